@@ -1,0 +1,227 @@
+/*
+ * trianglemix_hip.h -- C ABI of libtrianglemix_hip.so (MI355X / gfx950).
+ *
+ * The library replaces the TriangleMix hot path of the reference fork:
+ *   - the Python O(N^2) mask loops   (vllm/attention/trianglemix_attention.py:53-261)
+ *   - the eager masked attention     (vllm/attention/ascend_trianglemix.py:52-108)
+ * and is what a TORCH_LIBRARY binding in the style of the reference's
+ * csrc/rocm/torch_bindings.cpp:14-57 / csrc/rocm/ops.h:17-26 forwards to
+ * (tensors become pointers + strides, the current HIP stream is passed in).
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, enums as int.  No torch types.
+ *   - Every pointer named *_dev / in a struct marked (device) is device memory
+ *     of the current HIP device; *_host pointers are host memory.
+ *   - Every function returns TMX_OK (0) or a TMX_ERR_* code; tmx_last_error()
+ *     gives the message of the calling thread's last failure.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     Calls enqueue work and return; nothing synchronises with the host and
+ *     nothing is allocated on the device.
+ *   - Positions: request b owns query rows cu_seqlens_q[b] .. cu_seqlens_q[b+1]-1;
+ *     they are the LAST q_len positions of a sequence of seq_lens[b] tokens, so
+ *     query row r sits at position i = seq_lens[b] - q_len + r (the context of
+ *     seq_lens[b] - q_len earlier tokens lives only in the K/V storage).
+ *   - Mask predicate (reference trianglemix_attention.py:82-89,126-129,192-196):
+ *       allowed(i, j) = j <= i && (j <= si || i - j <= sl || N - i < last)
+ *     with N = seq_lens[b]; TMX_MODE_CAUSAL is j <= i (trianglemix_attention.py:218-219),
+ *     TMX_MODE_NONE attends to every key (ascend_trianglemix.py:96 with no mask).
+ */
+#ifndef TRIANGLEMIX_HIP_H_
+#define TRIANGLEMIX_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMX_ABI_VERSION 1
+
+enum {
+  TMX_OK = 0,
+  TMX_ERR_INVALID_ARG = 1,  /* bad pointer / size / enum value */
+  TMX_ERR_UNSUPPORTED = 2,  /* valid request the kernels do not cover (head size, dtype ...) */
+  TMX_ERR_HIP = 3,          /* a HIP runtime call failed */
+  TMX_ERR_CAPACITY = 4      /* caller-provided buffer capacities too small */
+};
+
+/* element types */
+enum { TMX_F32 = 0, TMX_BF16 = 1, TMX_F16 = 2, TMX_FP8_E4M3 = 3 };
+
+/* attention / index modes */
+enum { TMX_MODE_NONE = 0, TMX_MODE_CAUSAL = 1, TMX_MODE_TRIANGLE = 2 };
+
+/* dense mask kinds for tmx_dense_mask */
+enum {
+  TMX_MASK_STREAMING = 0, /* trianglemix_attention.py:53-91   */
+  TMX_MASK_LAST = 1,      /* trianglemix_attention.py:93-131  */
+  TMX_MASK_MIDDLE = 2,    /* trianglemix_attention.py:133-171 */
+  TMX_MASK_TRIANGLE = 3,  /* trianglemix_attention.py:173-198 */
+  TMX_MASK_DENSE = 4      /* trianglemix_attention.py:200-219 */
+};
+
+int tmx_abi_version(void);
+const char* tmx_last_error(void);
+
+/* Number of query rows per q-block the attention kernel uses for a given
+ * grouped-head ratio (num_heads / num_kv_heads), and its key-tile width.
+ * The index passed to tmx_attention must be built with exactly these. */
+int tmx_attention_block_m(int num_heads, int num_kv_heads);
+int tmx_attention_block_n(void);
+
+/* ------------------------------------------------------------------------
+ * Dense [n, n] mask materialisation -- API parity with
+ * TriangleMixMaskGenerator._create_*_mask and .get_attention_mask
+ * (trianglemix_attention.py:53-261).  Writes n rows of n elements of `dtype`
+ * (TMX_F32 / TMX_BF16 / TMX_F16) at out_dev with a row stride in elements.
+ * additive == 0: 1 where attended, 0 elsewhere;
+ * additive != 0: 0 where attended, -inf elsewhere (:254-258).
+ * ---------------------------------------------------------------------- */
+int tmx_dense_mask(void* out_dev, int64_t row_stride, int n, int si, int sl, int last,
+                   int kind, int dtype, int additive, void* stream);
+
+/* AscendNPUTriangleMixOptimizer.optimize_mask_for_npu (ascend_trianglemix.py:131-141):
+ * in place, every -inf of `count` contiguous elements becomes `value`. */
+int tmx_replace_neg_inf(void* mask_dev, int64_t count, int dtype, float value, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Packed block-sparse index.
+ *
+ * The batch is cut into q-blocks of block_m rows, request by request (a
+ * q-block never spans two requests).  For q-block r the index lists, in
+ * ascending order, every key tile t (keys [t*block_n, (t+1)*block_n)) that
+ * holds at least one attended (row, key) pair.  CSR layout, int32, shared by
+ * all heads:
+ *     row_ptr[R + 1], col_idx[nnz]
+ * plus per q-block metadata and a work list for the attention kernel:
+ *     qb_meta[R][2]    = (request b, first row offset inside the request)
+ *     part_ptr[R + 1]  = first partial slot of each q-block (see below)
+ *     items[I][4]      = (q-block, first entry in col_idx, tile count, partial slot)
+ *     split_qb[S]      = the q-blocks whose tile list was split, ascending
+ * A q-block with more than chunk_tiles tiles is split into pieces of at most
+ * chunk_tiles tiles; each piece is one item with its own partial slot, merged
+ * by the combine pass of tmx_attention.  Unsplit q-blocks have slot -1.  Items
+ * are ordered by q-block DESCENDING (the dense trailing rows start first),
+ * pieces of one q-block ascending.
+ * ---------------------------------------------------------------------- */
+typedef struct tmx_index_sizes_t {
+  int64_t num_qblocks; /* R */
+  int64_t nnz_tiles;   /* entries of col_idx */
+  int64_t num_items;   /* I */
+  int64_t num_partials;/* partial slots = part_ptr[R] */
+  int64_t num_split_qblocks; /* S */
+  int64_t max_tiles_per_qblock;
+} tmx_index_sizes_t;
+
+/* Host-side sizing from the host mirrors of the batch (vLLM keeps them:
+ * CommonAttentionMetadata.query_start_loc_cpu / seq_lens_cpu,
+ * vllm/v1/attention/backends/utils.py:53-60).  No device work. */
+int tmx_index_sizes(const int32_t* cu_seqlens_q_host, const int32_t* seq_lens_host, int batch,
+                    int si, int sl, int last, int block_m, int block_n, int mode, int tri_min_len,
+                    int chunk_tiles, tmx_index_sizes_t* out);
+
+typedef struct tmx_index_t {
+  /* all (device), int32, sized from tmx_index_sizes_t */
+  int32_t* row_ptr;   /* [R + 1] */
+  int32_t* col_idx;   /* [nnz] */
+  int32_t* qb_meta;   /* [R][2] */
+  int32_t* part_ptr;  /* [R + 1] */
+  int32_t* items;     /* [I][4] */
+  int32_t* split_qb;  /* [S] (may be NULL when S == 0) */
+  int32_t* totals;    /* [8]: R, nnz, I, partials, S, max tiles per q-block, 0, 0 -- as the kernel counted them */
+  int32_t* scratch;   /* [batch + 1 + 2 * (R + 1)] work area of the scan */
+  /* capacities the buffers above were allocated with */
+  int64_t cap_qblocks, cap_nnz, cap_items, cap_split;
+  int32_t block_m, block_n, mode, chunk_tiles;
+  int32_t si, sl, last, batch;
+  /* TMX_MODE_TRIANGLE only: requests with seq_len <= tri_min_len fall back to
+   * TMX_MODE_CAUSAL (the reference helper's length gate,
+   * trianglemix_attention.py:330-332, applied per request); 0 = no gate. */
+  int32_t tri_min_len;
+  int32_t reserved;
+} tmx_index_t;
+
+/* Builds the index on the device from the device copies of the batch
+ * description.  idx->block_m .. idx->batch and the capacities must be filled
+ * in by the caller; buffers must be at least as large as tmx_index_sizes says
+ * (checked against the capacities with the host-computed sizes when the host
+ * mirrors are given; pass NULL mirrors to skip that check). */
+int tmx_build_block_index(tmx_index_t* idx, const int32_t* cu_seqlens_q_dev, const int32_t* seq_lens_dev,
+                          const int32_t* cu_seqlens_q_host, const int32_t* seq_lens_host, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Masked attention (prefill and decode), grouped heads, ragged batch.
+ * Replaces AscendTriangleMixAttention.forward (ascend_trianglemix.py:52-108)
+ * and is the kernel behind AttentionImpl.forward
+ * (vllm/attention/backends/abstract.py:158-171; layout conventions of
+ * vllm/v1/attention/backends/rocm_attn.py:275-426).
+ * ---------------------------------------------------------------------- */
+typedef struct tmx_attention_args_t {
+  uint32_t struct_size; /* sizeof(tmx_attention_args_t), ABI check */
+  int32_t io_dtype;     /* q / k / v element type: TMX_BF16 or TMX_F16 */
+  int32_t out_dtype;    /* TMX_BF16 / TMX_F16 (== io_dtype) or TMX_F32 */
+  int32_t mode;         /* TMX_MODE_* ; must equal index->mode */
+  int32_t si, sl, last; /* must equal the index parameters */
+  float scale;          /* softmax scale */
+
+  int32_t batch, num_heads, num_kv_heads, head_dim;
+  int32_t total_q;      /* rows of q / out */
+
+  void* out;            /* (device) [total_q, num_heads, head_dim] */
+  int64_t out_stride_t, out_stride_h;
+  const void* q;        /* (device) [total_q, num_heads, head_dim] */
+  int64_t q_stride_t, q_stride_h; /* strides in elements; head_dim is contiguous */
+
+  /* Keys / values.  block_table == NULL: contiguous rows, request b's key j is
+   * row cu_seqlens_k[b] + j of k / v ([rows, num_kv_heads, head_dim]).
+   * block_table != NULL: paged cache [num_blocks, page_size, num_kv_heads, head_dim],
+   * request b's key j is in page block_table[b * block_table_stride + j / page_size],
+   * slot j % page_size; strides kv_stride_page / kv_stride_t / kv_stride_h. */
+  const void* k;
+  const void* v;
+  int64_t kv_stride_page, kv_stride_t, kv_stride_h;
+  const int32_t* block_table; /* (device) or NULL */
+  int64_t block_table_stride;
+  int32_t page_size;
+  const int32_t* cu_seqlens_k; /* (device) [batch + 1], contiguous mode only */
+
+  const int32_t* cu_seqlens_q; /* (device) [batch + 1] */
+  const int32_t* seq_lens;     /* (device) [batch] */
+
+  /* Optional additive bias added to the scaled scores before the softmax,
+   * indexed [position i][key j] and shared by requests and heads
+   * (the attn_mask argument of ascend_trianglemix.py:57,84,96-97). */
+  const void* bias;
+  int32_t bias_dtype; /* TMX_F32 / TMX_BF16 / TMX_F16 */
+  int64_t bias_stride; /* row stride in elements */
+  int32_t bias_rows, bias_cols;
+
+  const tmx_index_t* index;
+  int64_t num_items, num_partials, num_split_qblocks; /* from tmx_index_sizes */
+
+  /* Work area for split q-blocks (device, float32):
+   * partial_o [num_partials][num_heads][block_m][head_dim], partial_ml [num_partials][num_heads][block_m][2].
+   * May be NULL when num_partials == 0. */
+  float* partial_o;
+  float* partial_ml;
+} tmx_attention_args_t;
+
+int tmx_attention(const tmx_attention_args_t* args, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K/V cache write: copies key/value rows of this step into the paged cache,
+ * row t to flat slot slot_mapping[t] (slot = page * page_size + offset;
+ * negative slots are skipped).  Same contract as the reference's
+ * reshape_and_cache_flash op (csrc/cache_kernels.cu:282-355, called at
+ * vllm/v1/attention/backends/rocm_attn.py:345-354), 16-bit cache only.
+ * ---------------------------------------------------------------------- */
+int tmx_reshape_and_cache(const void* key, const void* value, int64_t kv_in_stride_t, int64_t kv_in_stride_h,
+                          void* key_cache, void* value_cache, int64_t cache_stride_page, int64_t cache_stride_t,
+                          int64_t cache_stride_h, const int64_t* slot_mapping_dev, int32_t num_tokens,
+                          int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRIANGLEMIX_HIP_H_ */

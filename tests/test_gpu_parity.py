@@ -1,0 +1,409 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+golden fixtures generated from the reference.  Needs an MI355X."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import trianglemix_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+# attention tolerance: fp32 kernel output vs the fp64 oracle on the same
+# 16-bit-rounded inputs.  P is rounded to 16 bits before the PV product, which
+# bounds the error by ~2^-9 * max|v| per row in the worst case.
+ATOL_F32_OUT = 1e-3 * 4
+
+
+def _pack(m):
+    return np.packbits(np.asarray(m) > 0, axis=None).tobytes()
+
+
+def _ops():
+    from vllm_trianglemix_amd import ops
+    return ops
+
+
+# ------------------------------------------------------------------ masks
+def test_dense_masks_match_golden(golden_masks):
+    ops = _ops()
+    kinds = {"streaming": "streaming", "last_mask": "last", "middle": "middle", "triangle": "triangle",
+             "dense": "dense"}
+    for c in golden_masks:
+        si, sl, last, n = c["si"], c["sl"], c["last"], c["n"]
+        for key, kind in kinds.items():
+            if key not in c:
+                continue
+            m = ops.dense_mask(n, si, sl, last, kind, DEV, torch.float32).cpu().numpy()
+            assert set(np.unique(m)) <= {0.0, 1.0}
+            assert int(m.sum()) == c[key]["nnz"], (c, key)
+            assert hashlib.sha256(_pack(m)).hexdigest() == c[key]["sha256"], (c, key)
+        for dt_name, dt in (("float32", torch.float32), ("bfloat16", torch.bfloat16)):
+            for tri in (False, True):
+                key = f"additive_{dt_name}_{'tri' if tri else 'dense'}"
+                if key not in c:
+                    continue
+                m = ops.dense_mask(n, si, sl, last, "triangle" if tri else "dense", DEV, dt, additive=True)
+                assert m.dtype == dt and tuple(m.shape) == (n, n)
+                mf = m.float().cpu().numpy()
+                assert np.all((mf == 0) | np.isneginf(mf))
+                assert hashlib.sha256(_pack(mf == 0)).hexdigest() == c[key]["sha256"]
+
+
+def test_dense_mask_dtypes_and_oracle_large():
+    ops = _ops()
+    for n, (si, sl, last) in ((3000, (4, 32, 64)), (777, (9, 100, 300)), (8, (0, 0, 0))):
+        want = orc.triangle_mask(n, si, sl, last)
+        for dt in (torch.float32, torch.bfloat16, torch.float16):
+            got = ops.dense_mask(n, si, sl, last, "triangle", DEV, dt).float().cpu().numpy()
+            assert np.array_equal(got > 0, want) and set(np.unique(got)) <= {0.0, 1.0}
+            add = ops.dense_mask(n, si, sl, last, "triangle", DEV, dt, additive=True).float().cpu().numpy()
+            assert np.array_equal(add == 0, want) and np.all(np.isneginf(add[~want]))
+
+
+def test_generator_api_and_helper(golden_selection):
+    from vllm_trianglemix_amd import (AscendNPUTriangleMixOptimizer, TriangleMixAttention, TriangleMixConfig,
+                                      TriangleMixMaskGenerator)
+    gen = TriangleMixMaskGenerator(TriangleMixConfig(4, 8, 16))
+    m = gen._create_streaming_mask(24, DEV, torch.float32).cpu().numpy()
+    assert m[10, 3] == 1 and m[15, 8] == 1 and m[15, 1] == 1 and m[15, 5] == 0 and m.sum() == 245
+    assert gen._create_last_mask(24, DEV, torch.float32).sum().item() == 55
+    assert gen._create_middle_mask(24, DEV, torch.float32).sum().item() == 0
+    assert gen._create_triangle_mask(24, DEV, torch.float32).sum().item() == 300
+    a = gen.get_attention_mask(24, 0, DEV, torch.float32, use_triangle=True)
+    assert a is gen.get_attention_mask(24, 0, DEV, torch.float32, use_triangle=True)
+    gen.clear_cache()
+    for rec in golden_selection["helper"]:
+        cfg = TriangleMixConfig(4, 8, 16, num_triangle_layers=rec["num_triangle_layers"],
+                                triangle_layer_indices=rec["triangle_layer_indices"])
+        helper = TriangleMixAttention(cfg, rec["num_layers"])
+        assert list(cfg.triangle_layer_indices) == rec["indices_after_init"]
+        for d in rec["decisions"]:
+            m = helper.get_attn_mask(d["n"], d["layer"], DEV)
+            if d["kind"] == "none":
+                assert m is None
+                continue
+            assert m.dtype == torch.float32
+            allowed = (m == 0).cpu().numpy()
+            if d["kind"] == "dense":
+                assert np.array_equal(allowed, np.tril(np.ones((d["n"], d["n"]), bool)))
+            else:
+                assert hashlib.sha256(_pack(allowed)).hexdigest() == rec["triangle_sha256"][str(d["n"])]
+    om = golden_selection["optimize_mask"]
+    m = torch.full((4, 4), float("-inf"), device=DEV)
+    m[0, 0] = 0.0
+    m[1, 0:2] = 0.0
+    m[2, 0:3] = 0.0
+    m[3, :] = 0.0
+    o = AscendNPUTriangleMixOptimizer.optimize_mask_for_npu(m)
+    assert np.array_equal(o.cpu().numpy(), np.asarray(om["out"], np.float32))
+    assert torch.isinf(m).any()  # the input is left alone
+    ob = AscendNPUTriangleMixOptimizer.optimize_mask_for_npu(m.bfloat16())
+    assert ob.dtype == torch.bfloat16 and not torch.isinf(ob).any()
+    assert ob.float().min().item() == torch.tensor(-1e6).bfloat16().float().item()
+
+
+# ------------------------------------------------------------------ index
+def _build(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk=4, gate=0):
+    cu_h = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    sl_h = np.asarray(seq_lens, np.int32)
+    cu = torch.from_numpy(cu_h).to(DEV)
+    sld = torch.from_numpy(sl_h).to(DEV)
+    idx = ops.build_block_index(cu, sld, cu_h, sl_h, si, sl, last, bm, bn, mode, chunk_tiles=chunk, tri_min_len=gate)
+    return idx, cu, sld
+
+
+def _check_index(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk):
+    idx, _, _ = _build(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk)
+    row_ptr, col_idx, qb_seq, qb_row0 = orc.block_index_closed_form(q_lens, seq_lens, si, sl, last, bm, bn, mode)
+    items, part_ptr = orc.work_items(row_ptr, chunk)
+    tot = idx.totals.cpu().numpy()
+    assert tot[0] == len(row_ptr) - 1 == idx.sizes.num_qblocks
+    assert tot[1] == len(col_idx) == idx.sizes.nnz_tiles
+    assert tot[2] == len(items) == idx.sizes.num_items
+    assert tot[3] == part_ptr[-1] == idx.sizes.num_partials
+    assert np.array_equal(idx.row_ptr.cpu().numpy(), row_ptr)
+    assert np.array_equal(idx.col_idx.cpu().numpy(), col_idx)
+    meta = idx.qb_meta.cpu().numpy()
+    assert np.array_equal(meta[:, 0], qb_seq) and np.array_equal(meta[:, 1], qb_row0)
+    assert np.array_equal(idx.part_ptr.cpu().numpy(), part_ptr)
+    assert np.array_equal(idx.items.cpu().numpy(), items)
+    split = [qb for qb in range(len(row_ptr) - 1) if part_ptr[qb + 1] > part_ptr[qb]]
+    assert np.array_equal(idx.split_qb.cpu().numpy(), np.asarray(split, np.int32))
+    assert tot[4] == len(split)
+    cnt = np.diff(row_ptr)
+    assert tot[5] == (cnt.max() if len(cnt) else 0) == idx.sizes.max_tiles_per_qblock
+
+
+def test_block_index_bit_exact_vs_oracle():
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    cases = [([24], [24], 4, 8, 16), ([70], [70], 4, 32, 64), ([300], [300], 4, 32, 64), ([1], [1], 0, 0, 0),
+             ([5, 1, 40], [50, 90, 40], 4, 32, 64), ([33, 0, 17], [33, 12, 100], 2, 5, 9), ([0], [7], 4, 32, 64),
+             ([1] * 9, [100, 2000, 1, 64, 65, 63, 33, 4097, 512], 4, 32, 64)]
+    for _ in range(20):
+        b = int(rng.integers(1, 6))
+        seq = [int(rng.integers(1, 700)) for _ in range(b)]
+        ql = [int(rng.integers(0, s + 1)) for s in seq]
+        cases.append((ql, seq, int(rng.integers(0, 9)), int(rng.integers(0, 40)), int(rng.integers(0, 70))))
+    for ql, seq, si, sl, last in cases:
+        for bm, bn in ((16, 32), (64, 32), (32, 32), (64, 64)):
+            for mode in (orc.MODE_TRIANGLE, orc.MODE_CAUSAL, orc.MODE_NONE):
+                _check_index(ops, ql, seq, si, sl, last, bm, bn, mode, chunk=3)
+    # bruteforce cross-check from the token bitmap (the definition of the index)
+    for ql, seq, si, sl, last in cases[:8]:
+        idx, _, _ = _build(ops, ql, seq, si, sl, last, 16, 32, orc.MODE_TRIANGLE)
+        bf = orc.block_index_bruteforce(ql, seq, si, sl, last, 16, 32, orc.MODE_TRIANGLE)
+        assert np.array_equal(idx.row_ptr.cpu().numpy(), bf[0]) and np.array_equal(idx.col_idx.cpu().numpy(), bf[1])
+
+
+def test_block_index_large_and_many_requests():
+    ops = _ops()
+    # more than 1024 requests and more than 1024 q-blocks: the scan runs several rounds
+    rng = np.random.default_rng(5)
+    seq = [int(x) for x in rng.integers(1, 300, size=2500)]
+    ql = [int(rng.integers(0, min(s, 40) + 1)) for s in seq]
+    _check_index(ops, ql, seq, 4, 32, 64, 16, 32, orc.MODE_TRIANGLE, chunk=2)
+    for n in (8192, 32768, 65536):
+        _check_index(ops, [n], [n], 4, 32, 64, 16, 32, orc.MODE_TRIANGLE, chunk=64)
+        _check_index(ops, [n], [n], 4, 32, 64, 64, 64, orc.MODE_TRIANGLE, chunk=64)
+    idx, _, _ = _build(ops, [32768], [32768], 4, 32, 64, 64, 64, orc.MODE_TRIANGLE, chunk=64)
+    assert idx.nnz_tiles == 2042
+    _check_index(ops, [4096], [4096], 4, 32, 64, 16, 32, orc.MODE_CAUSAL, chunk=64)
+    # the per-request length gate: short requests fall back to causal
+    idx, _, _ = _build(ops, [100, 3000], [100, 3000], 4, 32, 64, 16, 32, orc.MODE_TRIANGLE, chunk=64, gate=2048)
+    a = orc.block_index_closed_form([100], [100], 4, 32, 64, 16, 32, orc.MODE_CAUSAL)
+    b = orc.block_index_closed_form([3000], [3000], 4, 32, 64, 16, 32, orc.MODE_TRIANGLE)
+    assert np.array_equal(idx.col_idx.cpu().numpy(), np.concatenate([a[1], b[1]]))
+
+
+# ------------------------------------------------------------------ attention
+def _to_dev(x, dtype):
+    return torch.from_numpy(x).to(DEV).to(dtype)
+
+
+def _run_varlen(ops, q, k_list, v_list, q_lens, seq_lens, scale, mode, pattern, dtype=torch.bfloat16,
+                out_dtype=torch.float32, paged=False, page_size=16, bias=None, chunk=64, gate=0, q_pad=0):
+    """q: [T, H, D] float32 (already rounded); k_list/v_list: per-request [seq_len, Hkv, D]."""
+    T, H, D = q.shape
+    Hkv = k_list[0].shape[1]
+    si, sl, last = pattern
+    bm = ops.attention_block_m(H, Hkv)
+    idx, cu, sld = _build(ops, q_lens, seq_lens, si, sl, last, bm, ops.attention_block_n(), ops.MODES[mode], chunk,
+                          gate)
+    if q_pad:
+        # rows of a wider buffer (as a slice of a fused qkv projection would be)
+        buf = torch.zeros((T, H * D + q_pad), dtype=dtype, device=DEV)
+        buf[:, :H * D] = _to_dev(q, dtype).view(T, H * D)
+        qd = buf[:, :H * D].view(T, H, D)
+    else:
+        qd = _to_dev(q, dtype)
+    out = torch.full((T, H, D), float("nan"), dtype=out_dtype, device=DEV)
+    if paged:
+        nblk = sum((s + page_size - 1) // page_size for s in seq_lens) + 3
+        perm = np.random.default_rng(0).permutation(nblk).astype(np.int32)
+        kc = torch.zeros((nblk, page_size, Hkv, D), dtype=dtype, device=DEV)
+        vc = torch.zeros_like(kc)
+        maxb = max((s + page_size - 1) // page_size for s in seq_lens)
+        bt = np.zeros((len(seq_lens), maxb), np.int32)
+        nxt = 0
+        for b, s in enumerate(seq_lens):
+            for pb in range((s + page_size - 1) // page_size):
+                blk = int(perm[nxt])
+                nxt += 1
+                bt[b, pb] = blk
+                lo, hi = pb * page_size, min((pb + 1) * page_size, s)
+                kc[blk, :hi - lo] = _to_dev(k_list[b][lo:hi], dtype)
+                vc[blk, :hi - lo] = _to_dev(v_list[b][lo:hi], dtype)
+        ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=torch.from_numpy(bt).to(DEV), bias=bias)
+    else:
+        kd = _to_dev(np.concatenate(k_list, 0), dtype)
+        vd = _to_dev(np.concatenate(v_list, 0), dtype)
+        cu_k = torch.from_numpy(np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)).to(DEV)
+        ops.attention(qd, kd, vd, out, idx, cu, sld, scale, cu_seqlens_k=cu_k, bias=bias)
+    torch.cuda.synchronize()
+    return out.float().cpu().numpy()
+
+
+def _rand_case(seed, q_lens, seq_lens, H, Hkv, D):
+    T = int(sum(q_lens))
+    q = orc.seeded_normal(seed, (T, H, D))
+    ks = [orc.seeded_normal(seed + 100 + b, (s, Hkv, D)) for b, s in enumerate(seq_lens)]
+    vs = [orc.seeded_normal(seed + 200 + b, (s, Hkv, D)) for b, s in enumerate(seq_lens)]
+    return q, ks, vs
+
+
+def test_attention_matches_golden_eager(golden_attention):
+    """AscendTriangleMixAttention mirror vs the reference's own outputs."""
+    from vllm_trianglemix_amd import AscendTriangleMixAttention, TriangleMixConfig, TriangleMixMaskGenerator
+    meta, arrays = golden_attention
+    for c in meta["cases"]:
+        if c.get("run_dtype"):
+            continue
+        shape = (c["B"], c["N"], c["H"], c["D"])
+        q, k, v = (orc.seeded_normal(c["seed"] * 3 + t, shape) for t in range(3))
+        assert hashlib.sha256(q.tobytes() + k.tobytes() + v.tobytes()).hexdigest() == c["inputs_sha256"]
+        si, sl, last = c["cfg"]
+        cfg = TriangleMixConfig(si, sl, last, num_triangle_layers=c.get("ntl"))
+        qd, kd, vd = (_to_dev(x, torch.bfloat16) for x in (q, k, v))
+        if c["mask"] == "helper":
+            mod = AscendTriangleMixAttention(c["H"], c["D"], c["scale"], cfg, layer_idx=c["layer"],
+                                             num_layers=c["num_layers"])
+            out = mod(qd, kd, vd)
+        else:
+            gen = TriangleMixMaskGenerator(cfg)
+            am = gen.get_attention_mask(c["N"], 0, DEV, torch.bfloat16, use_triangle=(c["mask"] == "triangle"))
+            mod = AscendTriangleMixAttention(c["H"], c["D"], c["scale"])
+            out = mod(qd, kd, vd, attn_mask=am)  # the explicit-mask route: additive bias, no index pattern
+        assert out.shape == shape and out.is_contiguous() and out.dtype == torch.bfloat16
+        ref = arrays[c["name"]]
+        got = out.float().cpu().numpy()
+        assert not np.isnan(got).any(), c["name"]
+        err = np.abs(got - ref)
+        # bf16 output: 1e-3 plus half an output ulp (2^-8 relative)
+        assert np.all(err <= 1e-3 * 4 + np.abs(ref) * 2.0 ** -8), (c["name"], err.max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_varlen_gqa_vs_oracle(dtype):
+    ops = _ops()
+    cases = [
+        # q_lens, seq_lens, H, Hkv, D, mode, pattern
+        ([128], [128], 4, 4, 64, "triangle", (4, 8, 16)),
+        ([257], [257], 8, 2, 128, "triangle", (4, 32, 64)),
+        ([300, 1, 77], [300, 500, 130], 8, 2, 128, "triangle", (4, 32, 64)),
+        ([64, 200], [64, 200], 4, 2, 128, "causal", (0, 0, 0)),
+        ([50, 31], [50, 31], 2, 2, 64, "none", (0, 0, 0)),
+        ([500], [500], 16, 8, 128, "triangle", (4, 32, 64)),
+        ([100], [900], 8, 1, 128, "triangle", (4, 32, 64)),
+        ([1, 1, 1], [700, 33, 1], 8, 2, 128, "triangle", (4, 32, 64)),
+        ([40], [40], 3, 3, 64, "triangle", (0, 0, 0)),
+        ([90], [90], 12, 2, 64, "triangle", (2, 5, 9)),
+    ]
+    for ci, (ql, sl, H, Hkv, D, mode, pat) in enumerate(cases):
+        q, ks, vs = _rand_case(1000 + ci, ql, sl, H, Hkv, D)
+        if dtype == torch.float16:
+            q = q.astype(np.float16).astype(np.float32)
+            ks = [x.astype(np.float16).astype(np.float32) for x in ks]
+            vs = [x.astype(np.float16).astype(np.float32) for x in vs]
+        scale = D ** -0.5
+        ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], np.concatenate([[0], np.cumsum(ql)]),
+                                       sl, scale, mode, *pat)
+        for paged in (False, True):
+            got = _run_varlen(_ops(), q, ks, vs, ql, sl, scale, mode, pat, dtype=dtype, paged=paged,
+                              chunk=(4 if ci % 2 else 64), q_pad=(64 if ci % 3 == 0 else 0))
+            assert not np.isnan(got).any(), (ci, paged)
+            err = np.abs(got - ref).max()
+            assert err <= ATOL_F32_OUT, (ci, paged, err)
+
+
+def test_attention_split_and_combine_long():
+    """One long prompt: trailing rows are split into many pieces and merged."""
+    ops = _ops()
+    n, H, Hkv, D = 4096 + 37, 8, 2, 128
+    q, ks, vs = _rand_case(77, [n], [n], H, Hkv, D)
+    scale = D ** -0.5
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], [0, n], [n], scale, "triangle", 4, 32, 64)
+    for chunk in (8, 64, 1000):
+        got = _run_varlen(ops, q, ks, vs, [n], [n], scale, "triangle", (4, 32, 64), paged=True, chunk=chunk)
+        assert np.abs(got - ref).max() <= ATOL_F32_OUT, chunk
+    gb = _run_varlen(ops, q, ks, vs, [n], [n], scale, "triangle", (4, 32, 64), paged=True, out_dtype=torch.bfloat16)
+    assert np.all(np.abs(gb - ref) <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8)
+    refc = orc.varlen_gqa_attention(q[:, :2], lambda b: ks[b][:, :1], lambda b: vs[b][:, :1], [0, n], [n], scale,
+                                    "causal", 0, 0, 0)
+    gotc = _run_varlen(ops, q[:, :2].copy(), [ks[0][:, :1].copy()], [vs[0][:, :1].copy()], [n], [n], scale, "causal",
+                       (0, 0, 0), chunk=16)
+    assert np.abs(gotc - refc).max() <= ATOL_F32_OUT
+
+
+def test_attention_bias_and_fully_masked_rows():
+    ops = _ops()
+    n, H, D = 96, 2, 64
+    q, ks, vs = _rand_case(5, [n], [n], H, H, D)
+    scale = D ** -0.5
+    rng = np.random.default_rng(9)
+    bias = orc.bf16_round(rng.standard_normal((n, n)).astype(np.float32))
+    bias[rng.random((n, n)) < 0.3] = -np.inf
+    bias[7, :] = -np.inf  # a fully masked row: softmax over all -inf is NaN in the reference
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], [0, n], [n], scale, "none", 0, 0, 0, bias=bias)
+    for bdt in (torch.float32, torch.bfloat16):
+        got = _run_varlen(ops, q, ks, vs, [n], [n], scale, "none", (0, 0, 0),
+                          bias=torch.from_numpy(bias).to(DEV).to(bdt))
+        assert np.isnan(got[7]).all() and np.isnan(ref[7]).all()
+        ok = ~np.isnan(ref)
+        assert not np.isnan(got[ok]).any()
+        assert np.abs(got[ok] - ref[ok]).max() <= ATOL_F32_OUT
+    # bias on top of the triangle pattern (attn_mask + tri_mask in the reference)
+    bias2 = orc.bf16_round(rng.standard_normal((n, n)).astype(np.float32))
+    ref2 = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], [0, n], [n], scale, "triangle", 4, 8, 16,
+                                    bias=bias2)
+    got2 = _run_varlen(ops, q, ks, vs, [n], [n], scale, "triangle", (4, 8, 16), bias=torch.from_numpy(bias2).to(DEV))
+    assert np.abs(got2 - ref2).max() <= ATOL_F32_OUT
+
+
+def test_attention_linearity_in_v_at_full_size():
+    """Size-independent property at a BASELINE size (Qwen3-8B heads, N = 8192):
+    the output is linear in V, and rows inside the pattern's reach of a
+    constant V return that constant."""
+    ops = _ops()
+    n, H, Hkv, D = 8192, 32, 8, 128
+    g = torch.Generator(device="cpu").manual_seed(0)
+    q = torch.randn((n, H, D), generator=g).to(DEV).bfloat16()
+    k = torch.randn((n, Hkv, D), generator=g).to(DEV).bfloat16()
+    v1 = torch.randn((n, Hkv, D), generator=g).to(DEV).bfloat16()
+    v2 = torch.randn((n, Hkv, D), generator=g).to(DEV).bfloat16()
+    cu_h, sl_h = np.asarray([0, n], np.int32), np.asarray([n], np.int32)
+    cu, sld = torch.from_numpy(cu_h).to(DEV), torch.from_numpy(sl_h).to(DEV)
+    idx = ops.build_block_index(cu, sld, cu_h, sl_h, 4, 32, 64, ops.attention_block_m(H, Hkv), 32, 2)
+    outs = []
+    for v in (v1, v2, (v1.float() + v2.float()).bfloat16(), torch.ones_like(v1)):
+        o = torch.empty((n, H, D), dtype=torch.float32, device=DEV)
+        ops.attention(q, k, v, o, idx, cu, sld, D ** -0.5, cu_seqlens_k=cu)
+        outs.append(o)
+    lin = (outs[0] + outs[1] - outs[2]).abs().max().item()
+    assert lin < 0.05  # v1 + v2 is re-rounded to bf16: 2^-8 relative on values up to ~8
+    assert (outs[3] - 1.0).abs().max().item() < 1e-2
+    # spot-check rows against the oracle (first, middle, last-region rows)
+    rows = [0, 5, 40, 4000, 8191 - 70, 8191 - 10, 8191]
+    qn, kn, vn = q.float().cpu().numpy(), k.float().cpu().numpy(), v1.float().cpu().numpy()
+    got = outs[0].cpu().numpy()
+    for i in rows:
+        allow = orc.triangle_mask(n, 4, 32, 64)[i] if n <= 8192 else None
+        for h in (0, 13, 31):
+            s = (kn[:, h // 4, :].astype(np.float64) @ qn[i, h].astype(np.float64)) * D ** -0.5
+            s[~allow] = -np.inf
+            p = np.exp(s - s.max())
+            p /= p.sum()
+            assert np.abs(p @ vn[:, h // 4, :].astype(np.float64) - got[i, h]).max() <= ATOL_F32_OUT
+
+
+def test_reshape_and_cache_and_errors():
+    ops = _ops()
+    from vllm_trianglemix_amd._lib import TmxError
+    T, Hkv, D, ps, nb = 37, 2, 128, 16, 9
+    key = torch.randn((T, Hkv, D), device=DEV).bfloat16()
+    val = torch.randn((T, Hkv, D), device=DEV).bfloat16()
+    kc = torch.zeros((nb, ps, Hkv, D), dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    slots = torch.randperm(nb * ps)[:T].to(torch.int64)
+    slots[3] = -1
+    ops.reshape_and_cache(key, val, kc, vc, slots.to(DEV))
+    kf, vf = kc.view(nb * ps, Hkv, D), vc.view(nb * ps, Hkv, D)
+    for t in range(T):
+        if slots[t] < 0:
+            continue
+        assert torch.equal(kf[slots[t]], key[t]) and torch.equal(vf[slots[t]], val[t])
+    assert kc.float().abs().sum().item() > 0
+    written = torch.zeros(nb * ps, dtype=torch.bool)
+    written[slots[slots >= 0]] = True
+    assert kf[~written.to(DEV)].abs().sum().item() == 0
+    # loud failures: CPU tensors, wrong index geometry
+    with pytest.raises(RuntimeError):
+        ops.dense_mask(8, 4, 32, 64, "triangle", "cpu", torch.float32)
+    idx, cu, sld = _build(ops, [64], [64], 4, 32, 64, 64, 64, 2)
+    q = torch.zeros((64, 4, 128), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(TmxError):
+        ops.attention(q, q, q, torch.empty_like(q), idx, cu, sld, 1.0, cu_seqlens_k=cu)

@@ -1,0 +1,70 @@
+// Error reporting, version and host-side index sizing of libtrianglemix_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <climits>
+
+#include "tmx_common.h"
+
+namespace tmx {
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+}  // namespace tmx
+
+extern "C" {
+
+int tmx_abi_version(void) { return TMX_ABI_VERSION; }
+
+const char* tmx_last_error(void) { return tmx::g_error; }
+
+int tmx_attention_block_m(int num_heads, int num_kv_heads) {
+  if (num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0) return -1;
+  return tmx::block_m_for_group(num_heads / num_kv_heads);
+}
+
+int tmx_attention_block_n(void) { return tmx::kBlockN; }
+
+int tmx_index_sizes(const int32_t* cu_q, const int32_t* seq_lens, int batch, int si, int sl, int last,
+                    int block_m, int block_n, int mode, int tri_min_len, int chunk_tiles,
+                    tmx_index_sizes_t* out) {
+  TMX_CHECK_ARG(out != nullptr, "tmx_index_sizes: out is NULL");
+  TMX_CHECK_ARG(batch >= 0 && (batch == 0 || (cu_q && seq_lens)), "tmx_index_sizes: NULL batch arrays");
+  TMX_CHECK_ARG(block_m > 0 && block_n > 0 && chunk_tiles > 0, "tmx_index_sizes: block sizes must be positive");
+  TMX_CHECK_ARG(mode >= TMX_MODE_NONE && mode <= TMX_MODE_TRIANGLE, "tmx_index_sizes: bad mode %d", mode);
+  int64_t R = 0, nnz = 0, items = 0, parts = 0, split = 0, mx = 0;
+  for (int b = 0; b < batch; ++b) {
+    const int ql = cu_q[b + 1] - cu_q[b];
+    const int n = seq_lens[b];
+    TMX_CHECK_ARG(ql >= 0 && n >= ql, "tmx_index_sizes: request %d has q_len %d, seq_len %d", b, ql, n);
+    const int ctx = n - ql;
+    for (int r0 = 0; r0 < ql; r0 += block_m) {
+      const int r1 = tmx::imin(r0 + block_m, ql);
+      const int cnt = tmx::tile_ranges(tmx::effective_mode(mode, n, tri_min_len), ctx + r0, ctx + r1 - 1, n, si, sl, last, block_n).count();
+      const int pieces = tmx::imax(1, tmx::ceil_div(cnt, chunk_tiles));
+      ++R;
+      nnz += cnt;
+      items += pieces;
+      if (pieces > 1) {
+        parts += pieces;
+        ++split;
+      }
+      if (cnt > mx) mx = cnt;
+    }
+  }
+  TMX_CHECK_ARG(nnz < INT_MAX && items < INT_MAX && R < INT_MAX, "tmx_index_sizes: index exceeds int32 range");
+  out->num_qblocks = R;
+  out->nnz_tiles = nnz;
+  out->num_items = items;
+  out->num_partials = parts;
+  out->num_split_qblocks = split;
+  out->max_tiles_per_qblock = mx;
+  return TMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// Shared host/device definitions of the TriangleMix HIP library (gfx950).
+//
+// The closed forms below are the single statement of the mask pattern used by
+// every kernel and by the host-side sizing code.  They follow the reference
+// predicate (vllm/attention/trianglemix_attention.py:82-89, 126-129, 192-196):
+//   allowed(i, j) = j <= i && (j <= si || i - j <= sl || N - i < last)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/trianglemix_hip.h"
+
+#define TMX_HD __host__ __device__ __forceinline__
+
+namespace tmx {
+
+constexpr int kBlockN = 32;     // keys per tile of the attention kernel
+constexpr int kWavesPerWG = 4;  // waves of one attention workgroup
+constexpr float kLog2e = 1.4426950408889634f;
+
+TMX_HD int ceil_div(int a, int b) { return (a + b - 1) / b; }
+TMX_HD int imin(int a, int b) { return a < b ? a : b; }
+TMX_HD int imax(int a, int b) { return a > b ? a : b; }
+
+TMX_HD int gcd_int(int a, int b) {
+  while (b) {
+    int t = a % b;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
+// Heads of one K/V group handled by one workgroup, and 16-row blocks per workgroup.
+TMX_HD int heads_per_wg(int group) { return gcd_int(group, kWavesPerWG); }
+TMX_HD int block_m_for_group(int group) { return 16 * (kWavesPerWG / heads_per_wg(group)); }
+
+// The triangle pattern applies to requests longer than the gate only.
+TMX_HD int effective_mode(int mode, int n, int tri_min_len) {
+  return (mode == TMX_MODE_TRIANGLE && n <= tri_min_len) ? TMX_MODE_CAUSAL : mode;
+}
+
+TMX_HD bool allowed(int mode, int i, int j, int n, int si, int sl, int last) {
+  if (mode == TMX_MODE_NONE) return true;
+  if (j > i) return false;
+  if (mode == TMX_MODE_CAUSAL) return true;
+  return j <= si || (i - j) <= sl || (n - i) < last;
+}
+
+// Key-tile set of the query positions i_min..i_max (a q-block, or one wave's
+// rows) of a sequence of n keys: at most two inclusive, ascending, disjoint
+// tile ranges [a0, a1] and [b0, b1]; a range with hi < lo is empty.
+struct TileRanges {
+  int a0, a1, b0, b1;
+  TMX_HD int count() const { return imax(0, a1 - a0 + 1) + imax(0, b1 - b0 + 1); }
+  TMX_HD int tile_at(int e) const {
+    const int la = imax(0, a1 - a0 + 1);
+    return e < la ? a0 + e : b0 + (e - la);
+  }
+  TMX_HD bool contains(int t) const { return (t >= a0 && t <= a1) || (t >= b0 && t <= b1); }
+};
+
+TMX_HD TileRanges tile_ranges(int mode, int i_min, int i_max, int n, int si, int sl, int last, int bn) {
+  TileRanges r{0, -1, 0, -1};
+  const int nt = ceil_div(n, bn);
+  if (nt <= 0 || i_max < i_min) return r;
+  if (mode == TMX_MODE_NONE) {
+    r.a1 = nt - 1;
+    return r;
+  }
+  const int t_diag = i_max / bn;
+  if (mode == TMX_MODE_CAUSAL || (n - i_max) < last) {
+    r.a1 = t_diag;
+    return r;
+  }
+  const int a_hi = imin(i_max, si);
+  const bool has_sink = a_hi >= 0;
+  if (has_sink) r.a1 = a_hi / bn;
+  if (sl >= 0) {
+    const int b_lo = imax(0, i_min - sl) / bn;
+    if (has_sink && b_lo <= r.a1 + 1) {
+      r.a1 = imax(r.a1, t_diag);
+    } else if (has_sink) {
+      r.b0 = b_lo;
+      r.b1 = t_diag;
+    } else {
+      r.a0 = b_lo;
+      r.a1 = t_diag;
+    }
+  }
+  return r;
+}
+
+void set_error(const char* fmt, ...);
+
+#define TMX_CHECK_ARG(cond, ...)      \
+  do {                                \
+    if (!(cond)) {                    \
+      tmx::set_error(__VA_ARGS__);    \
+      return TMX_ERR_INVALID_ARG;     \
+    }                                 \
+  } while (0)
+
+#define TMX_CHECK_SUPPORTED(cond, ...) \
+  do {                                 \
+    if (!(cond)) {                     \
+      tmx::set_error(__VA_ARGS__);     \
+      return TMX_ERR_UNSUPPORTED;      \
+    }                                  \
+  } while (0)
+
+#define TMX_CHECK_HIP(expr)                                                        \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      tmx::set_error("%s failed: %s", #expr, hipGetErrorString(e_));               \
+      return TMX_ERR_HIP;                                                          \
+    }                                                                              \
+  } while (0)
+
+}  // namespace tmx

@@ -1,0 +1,257 @@
+// Packed block-sparse index builder (integer work, coalesced int32 stores).
+//
+// Replaces the O(N^2) Python mask loops of the reference
+// (vllm/attention/trianglemix_attention.py:82-89, 126-129) with the closed
+// form of the pattern evaluated per q-block: every q-block's key-tile set is
+// at most two tile ranges, so the CSR index, the per-q-block metadata and the
+// work list come out of one scan pass and one fill pass.
+//
+//   pass 1 (one workgroup, 1024 threads): q-blocks per request -> request of
+//           each q-block -> tile / piece / partial / split counts -> four
+//           exclusive scans (row_ptr, piece_ptr, part_ptr, split position).
+//   pass 2 (one wave per q-block): lanes write consecutive col_idx entries and
+//           the q-block's work items.
+#include "tmx_common.h"
+
+namespace tmx {
+
+struct Int4 {
+  int x, y, z, w;
+};
+__device__ __forceinline__ Int4 operator+(const Int4& a, const Int4& b) {
+  return Int4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+}
+
+__device__ __forceinline__ Int4 shfl_up4(const Int4& v, int delta) {
+  return Int4{__shfl_up(v.x, delta, 64), __shfl_up(v.y, delta, 64), __shfl_up(v.z, delta, 64),
+              __shfl_up(v.w, delta, 64)};
+}
+
+// Exclusive scan of one Int4 per thread over a 1024-thread workgroup.
+// Returns the exclusive prefix; `total` receives the workgroup sum.
+__device__ Int4 block_exclusive_scan(Int4 v, Int4* wave_sums /* LDS [16] */, Int4& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Int4 inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    Int4 o = shfl_up4(inc, d);
+    if (lane >= d) inc = inc + o;
+  }
+  if (lane == 63) wave_sums[wave] = inc;
+  __syncthreads();
+  Int4 base{0, 0, 0, 0};
+  Int4 tot{0, 0, 0, 0};
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) base = base + wave_sums[w];
+    tot = tot + wave_sums[w];
+  }
+  __syncthreads();
+  total = tot;
+  Int4 exc{inc.x - v.x, inc.y - v.y, inc.z - v.z, inc.w - v.w};
+  return base + exc;
+}
+
+struct IndexParams {
+  const int32_t* cu_q;
+  const int32_t* seq_lens;
+  int32_t* row_ptr;
+  int32_t* col_idx;
+  int32_t* qb_meta;
+  int32_t* part_ptr;
+  int32_t* items;
+  int32_t* split_qb;
+  int32_t* totals;
+  int32_t* seq_qb_ptr;  // scratch [batch + 1]
+  int32_t* piece_ptr;   // scratch [R + 1]
+  int batch, block_m, block_n, mode, chunk, si, sl, last, tri_min_len;
+  int cap_qblocks, cap_nnz, cap_items, cap_split;
+};
+
+__global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
+  __shared__ Int4 wave_sums[16];
+  __shared__ int s_num_qblocks;
+  const int tid = threadIdx.x;
+
+  // (a) q-blocks per request -> seq_qb_ptr
+  int carry = 0;
+  for (int base = 0; base < p.batch; base += 1024) {
+    const int b = base + tid;
+    int nqb = 0;
+    if (b < p.batch) nqb = ceil_div(imax(0, p.cu_q[b + 1] - p.cu_q[b]), p.block_m);
+    Int4 tot;
+    Int4 e = block_exclusive_scan(Int4{nqb, 0, 0, 0}, wave_sums, tot);
+    if (b < p.batch) p.seq_qb_ptr[b] = carry + e.x;
+    carry += tot.x;
+  }
+  if (tid == 0) {
+    p.seq_qb_ptr[p.batch] = carry;
+    s_num_qblocks = carry;
+  }
+  __syncthreads();
+  const int R = s_num_qblocks;
+
+  // (b) per q-block counts -> row_ptr / piece_ptr / part_ptr / split positions
+  Int4 run{0, 0, 0, 0};
+  int max_tiles = 0;
+  for (int base = 0; base < R; base += 1024) {
+    const int qb = base + tid;
+    Int4 v{0, 0, 0, 0};
+    int b = 0, r0 = 0;
+    if (qb < R) {
+      int lo = 0, hi = p.batch;  // last b with seq_qb_ptr[b] <= qb
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (p.seq_qb_ptr[mid] <= qb) lo = mid; else hi = mid;
+      }
+      b = lo;
+      r0 = (qb - p.seq_qb_ptr[b]) * p.block_m;
+      const int ql = p.cu_q[b + 1] - p.cu_q[b];
+      const int n = p.seq_lens[b];
+      const int ctx = n - ql;
+      const int r1 = imin(r0 + p.block_m, ql);
+      const int cnt = tile_ranges(effective_mode(p.mode, n, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, p.si, p.sl, p.last, p.block_n).count();
+      const int pieces = imax(1, ceil_div(cnt, p.chunk));
+      v = Int4{cnt, pieces, pieces > 1 ? pieces : 0, pieces > 1 ? 1 : 0};
+      max_tiles = imax(max_tiles, cnt);
+    }
+    Int4 tot;
+    Int4 e = block_exclusive_scan(v, wave_sums, tot);
+    e = e + run;
+    if (qb < R && qb < p.cap_qblocks) {
+      p.row_ptr[qb] = e.x;
+      p.piece_ptr[qb] = e.y;
+      p.part_ptr[qb] = e.z;
+      p.qb_meta[2 * qb] = b;
+      p.qb_meta[2 * qb + 1] = r0;
+      if (v.w && e.w < p.cap_split) p.split_qb[e.w] = qb;
+    }
+    run = run + tot;
+  }
+  // workgroup max of max_tiles (reuse the scan scratch)
+  __syncthreads();
+  int m = max_tiles;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = imax(m, __shfl_xor(m, d, 64));
+  if ((tid & 63) == 0) wave_sums[tid >> 6].x = m;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w) m = imax(m, wave_sums[w].x);
+    if (R <= p.cap_qblocks) {
+      p.row_ptr[R] = run.x;
+      p.piece_ptr[R] = run.y;
+      p.part_ptr[R] = run.z;
+    }
+    p.totals[0] = R;
+    p.totals[1] = run.x;
+    p.totals[2] = run.y;
+    p.totals[3] = run.z;
+    p.totals[4] = run.w;
+    p.totals[5] = m;
+    p.totals[6] = 0;
+    p.totals[7] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void index_fill_kernel(IndexParams p) {
+  const int lane = threadIdx.x & 63;
+  const int qb = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int num_qblocks = p.totals[0];  // counted by index_scan_kernel earlier on this stream
+  if (num_qblocks > p.cap_qblocks || qb >= num_qblocks) return;
+  const int b = p.qb_meta[2 * qb], r0 = p.qb_meta[2 * qb + 1];
+  const int ql = p.cu_q[b + 1] - p.cu_q[b];
+  const int n = p.seq_lens[b];
+  const int ctx = n - ql;
+  const int r1 = imin(r0 + p.block_m, ql);
+  const TileRanges tr = tile_ranges(effective_mode(p.mode, n, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, p.si, p.sl, p.last, p.block_n);
+  const int cnt = tr.count();
+  const int start = p.row_ptr[qb];
+  for (int e = lane; e < cnt; e += 64)
+    if (start + e < p.cap_nnz) p.col_idx[start + e] = tr.tile_at(e);
+  // work items: q-blocks descending, pieces ascending
+  const int pieces = imax(1, ceil_div(cnt, p.chunk));
+  const int total_pieces = p.piece_ptr[num_qblocks];
+  const int first_item = total_pieces - p.piece_ptr[qb] - pieces;
+  const int slot0 = p.part_ptr[qb];
+  for (int pc = lane; pc < pieces; pc += 64) {
+    const int it = first_item + pc;
+    if (it < p.cap_items) {
+      const int s = start + pc * p.chunk;
+      int4 rec;
+      rec.x = qb;
+      rec.y = s;
+      rec.z = imax(0, imin(p.chunk, start + cnt - s));
+      rec.w = pieces > 1 ? slot0 + pc : -1;
+      reinterpret_cast<int4*>(p.items)[it] = rec;
+    }
+  }
+}
+
+}  // namespace tmx
+
+extern "C" int tmx_build_block_index(tmx_index_t* idx, const int32_t* cu_q_dev, const int32_t* seq_lens_dev,
+                                     const int32_t* cu_q_host, const int32_t* seq_lens_host, void* stream) {
+  TMX_CHECK_ARG(idx != nullptr, "tmx_build_block_index: idx is NULL");
+  TMX_CHECK_ARG(idx->batch >= 0, "tmx_build_block_index: batch < 0");
+  TMX_CHECK_ARG(idx->block_m > 0 && idx->block_n > 0 && idx->chunk_tiles > 0,
+                "tmx_build_block_index: block_m / block_n / chunk_tiles must be positive");
+  TMX_CHECK_ARG(idx->mode >= TMX_MODE_NONE && idx->mode <= TMX_MODE_TRIANGLE, "tmx_build_block_index: bad mode %d",
+                idx->mode);
+  TMX_CHECK_ARG(idx->totals && idx->scratch && idx->row_ptr && idx->part_ptr,
+                "tmx_build_block_index: NULL totals / scratch / row_ptr / part_ptr");
+  TMX_CHECK_ARG(idx->batch == 0 || (cu_q_dev && seq_lens_dev), "tmx_build_block_index: NULL device batch arrays");
+  TMX_CHECK_ARG(idx->cap_qblocks >= 0 && idx->cap_nnz >= 0 && idx->cap_items >= 0 && idx->cap_split >= 0,
+                "tmx_build_block_index: negative capacity");
+  TMX_CHECK_ARG((idx->cap_qblocks == 0 || idx->qb_meta) && (idx->cap_nnz == 0 || idx->col_idx) &&
+                    (idx->cap_items == 0 || idx->items) && (idx->cap_split == 0 || idx->split_qb),
+                "tmx_build_block_index: NULL buffer with non-zero capacity");
+  TMX_CHECK_ARG((reinterpret_cast<uintptr_t>(idx->items) & 15) == 0, "tmx_build_block_index: items must be 16-byte aligned");
+  if (cu_q_host && seq_lens_host) {
+    tmx_index_sizes_t sz;
+    int rc = tmx_index_sizes(cu_q_host, seq_lens_host, idx->batch, idx->si, idx->sl, idx->last, idx->block_m,
+                             idx->block_n, idx->mode, idx->tri_min_len, idx->chunk_tiles, &sz);
+    if (rc != TMX_OK) return rc;
+    if (sz.num_qblocks > idx->cap_qblocks || sz.nnz_tiles > idx->cap_nnz || sz.num_items > idx->cap_items ||
+        sz.num_split_qblocks > idx->cap_split) {
+      tmx::set_error("tmx_build_block_index: capacities (%lld q-blocks, %lld tiles, %lld items, %lld split) below "
+                     "the required (%lld, %lld, %lld, %lld)",
+                     (long long)idx->cap_qblocks, (long long)idx->cap_nnz, (long long)idx->cap_items,
+                     (long long)idx->cap_split, (long long)sz.num_qblocks, (long long)sz.nnz_tiles,
+                     (long long)sz.num_items, (long long)sz.num_split_qblocks);
+      return TMX_ERR_CAPACITY;
+    }
+  }
+  tmx::IndexParams p;
+  p.cu_q = cu_q_dev;
+  p.seq_lens = seq_lens_dev;
+  p.row_ptr = idx->row_ptr;
+  p.col_idx = idx->col_idx;
+  p.qb_meta = idx->qb_meta;
+  p.part_ptr = idx->part_ptr;
+  p.items = idx->items;
+  p.split_qb = idx->split_qb;
+  p.totals = idx->totals;
+  p.seq_qb_ptr = idx->scratch;
+  p.piece_ptr = idx->scratch + idx->batch + 1;
+  p.batch = idx->batch;
+  p.block_m = idx->block_m;
+  p.block_n = idx->block_n;
+  p.mode = idx->mode;
+  p.chunk = idx->chunk_tiles;
+  p.si = idx->si;
+  p.sl = idx->sl;
+  p.last = idx->last;
+  p.tri_min_len = idx->tri_min_len;
+  p.cap_qblocks = (int)idx->cap_qblocks;
+  p.cap_nnz = (int)idx->cap_nnz;
+  p.cap_items = (int)idx->cap_items;
+  p.cap_split = (int)idx->cap_split;
+  hipStream_t s = (hipStream_t)stream;
+  tmx::index_scan_kernel<<<1, 1024, 0, s>>>(p);
+  TMX_CHECK_HIP(hipGetLastError());
+  if (idx->cap_qblocks > 0) {
+    const int nq = (int)idx->cap_qblocks;  // upper bound of the q-block count; surplus waves exit
+    tmx::index_fill_kernel<<<tmx::ceil_div(nq, 4), 256, 0, s>>>(p);
+    TMX_CHECK_HIP(hipGetLastError());
+  }
+  return TMX_OK;
+}

@@ -1,0 +1,286 @@
+"""Tensor-level wrappers over the C ABI (the counterpart of the reference's
+``vllm/_custom_ops.py:153-196``: outputs are allocated here, the native code
+only fills them).  Every tensor must live on a HIP device; torch is used for
+device memory and the current stream only."""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (AttentionArgs, Index, IndexSizes, TMX_BF16, TMX_F16, TMX_F32, TMX_MODE_CAUSAL, TMX_MODE_NONE,
+                   TMX_MODE_TRIANGLE, check)
+
+DEFAULT_CHUNK_TILES = 64  # key tiles per work item before a q-block is split (64 x 32 = 2048 keys)
+
+_DTYPE = {torch.float32: TMX_F32, torch.bfloat16: TMX_BF16, torch.float16: TMX_F16}
+MODES = {"none": TMX_MODE_NONE, "causal": TMX_MODE_CAUSAL, "triangle": TMX_MODE_TRIANGLE}
+MASK_KINDS = {"streaming": 0, "last": 1, "middle": 2, "triangle": 3, "dense": 4}
+
+
+def _require_gpu(t: torch.Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a tensor on a HIP device (the TriangleMix path has no CPU fallback)")
+
+
+def _device_of(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(f"TriangleMix kernels run on HIP devices only, got device '{device}' "
+                           "(there is no CPU fallback)")
+    return device
+
+
+def _stream(device: torch.device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype not in _DTYPE:
+        raise RuntimeError(f"unsupported dtype {dtype} (float32, bfloat16, float16)")
+    return _DTYPE[dtype]
+
+
+# --------------------------------------------------------------------------- masks
+def dense_mask(n: int, si: int, sl: int, last: int, kind: str, device, dtype: torch.dtype,
+               additive: bool = False) -> torch.Tensor:
+    """``[n, n]`` mask of ``dtype`` on ``device``: 1/0 values, or 0/-inf when
+    ``additive`` (reference trianglemix_attention.py:53-261)."""
+    device = _device_of(device)
+    out = torch.empty((n, n), dtype=dtype, device=device)
+    with torch.cuda.device(device):
+        check(_lib.load().tmx_dense_mask(_ptr(out), n, n, si, sl, last, MASK_KINDS[kind], dtype_code(dtype),
+                                         int(additive), _stream(device)))
+    return out
+
+
+def replace_neg_inf_(mask: torch.Tensor, value: float) -> torch.Tensor:
+    """In place: -inf -> ``value`` (reference ascend_trianglemix.py:131-141)."""
+    _require_gpu(mask, "mask")
+    if not mask.is_contiguous():
+        raise RuntimeError("mask must be contiguous")
+    with torch.cuda.device(mask.device):
+        check(_lib.load().tmx_replace_neg_inf(_ptr(mask), mask.numel(), dtype_code(mask.dtype), float(value),
+                                              _stream(mask.device)))
+    return mask
+
+
+# --------------------------------------------------------------------------- index
+def attention_block_m(num_heads: int, num_kv_heads: int) -> int:
+    bm = _lib.load().tmx_attention_block_m(num_heads, num_kv_heads)
+    if bm <= 0:
+        raise RuntimeError(f"num_heads {num_heads} must be a positive multiple of num_kv_heads {num_kv_heads}")
+    return bm
+
+
+def attention_block_n() -> int:
+    return _lib.load().tmx_attention_block_n()
+
+
+def index_sizes(cu_seqlens_q_cpu, seq_lens_cpu, si: int, sl: int, last: int, block_m: int, block_n: int,
+                mode: int, chunk_tiles: int = DEFAULT_CHUNK_TILES, tri_min_len: int = 0) -> IndexSizes:
+    """Exact buffer sizes of the index, from the host copies of the batch."""
+    cu = np.ascontiguousarray(np.asarray(cu_seqlens_q_cpu), dtype=np.int32)
+    sl_ = np.ascontiguousarray(np.asarray(seq_lens_cpu), dtype=np.int32)
+    if cu.ndim != 1 or sl_.ndim != 1 or cu.shape[0] != sl_.shape[0] + 1:
+        raise RuntimeError("cu_seqlens_q must have one more entry than seq_lens")
+    sz = IndexSizes()
+    check(_lib.load().tmx_index_sizes(cu.ctypes.data_as(ctypes.c_void_p), sl_.ctypes.data_as(ctypes.c_void_p),
+                                      int(sl_.shape[0]), si, sl, last, block_m, block_n, mode, tri_min_len,
+                                      chunk_tiles,
+                                      ctypes.byref(sz)))
+    return sz
+
+
+@dataclass
+class BlockIndex:
+    """Device-resident packed block-sparse index + work list (all int32)."""
+    row_ptr: torch.Tensor
+    col_idx: torch.Tensor
+    qb_meta: torch.Tensor
+    part_ptr: torch.Tensor
+    items: torch.Tensor
+    split_qb: torch.Tensor
+    totals: torch.Tensor
+    scratch: torch.Tensor
+    sizes: IndexSizes
+    c: Index
+    batch: int
+    block_m: int
+    block_n: int
+    mode: int
+    si: int
+    sl: int
+    last: int
+    chunk_tiles: int
+    tri_min_len: int = 0
+
+    @property
+    def num_qblocks(self) -> int:
+        return int(self.sizes.num_qblocks)
+
+    @property
+    def nnz_tiles(self) -> int:
+        return int(self.sizes.nnz_tiles)
+
+
+def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seqlens_q_cpu, seq_lens_cpu,
+                      si: int, sl: int, last: int, block_m: int, block_n: int, mode: int,
+                      chunk_tiles: int = DEFAULT_CHUNK_TILES, tri_min_len: int = 0) -> BlockIndex:
+    """Build the packed block-sparse index on the device (two launches, no
+    host synchronisation; buffer sizes come from the host copies)."""
+    _require_gpu(cu_seqlens_q, "cu_seqlens_q")
+    _require_gpu(seq_lens, "seq_lens")
+    if cu_seqlens_q.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise RuntimeError("cu_seqlens_q and seq_lens must be int32")
+    dev = cu_seqlens_q.device
+    cu_h = np.ascontiguousarray(np.asarray(cu_seqlens_q_cpu), dtype=np.int32)
+    sl_h = np.ascontiguousarray(np.asarray(seq_lens_cpu), dtype=np.int32)
+    batch = int(sl_h.shape[0])
+    if seq_lens.numel() != batch or cu_seqlens_q.numel() != batch + 1:
+        raise RuntimeError("device and host batch descriptions differ in length")
+    sz = index_sizes(cu_h, sl_h, si, sl, last, block_m, block_n, mode, chunk_tiles, tri_min_len)
+    R, nnz, n_items, n_split = (int(sz.num_qblocks), int(sz.nnz_tiles), int(sz.num_items),
+                                int(sz.num_split_qblocks))
+
+    def i32(n):
+        return torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+
+    row_ptr, col_idx, qb_meta, part_ptr = i32(R + 1), i32(nnz), i32(2 * R), i32(R + 1)
+    items = torch.empty((max(n_items, 1), 4), dtype=torch.int32, device=dev)
+    split_qb, totals, scratch = i32(n_split), i32(8), i32(batch + 1 + 2 * (R + 1))
+    c = Index()
+    c.row_ptr, c.col_idx, c.qb_meta, c.part_ptr = (row_ptr.data_ptr(), col_idx.data_ptr(), qb_meta.data_ptr(),
+                                                    part_ptr.data_ptr())
+    c.items, c.split_qb, c.totals, c.scratch = (items.data_ptr(), split_qb.data_ptr(), totals.data_ptr(),
+                                                scratch.data_ptr())
+    c.cap_qblocks, c.cap_nnz, c.cap_items, c.cap_split = R, nnz, n_items, n_split
+    c.block_m, c.block_n, c.mode, c.chunk_tiles = block_m, block_n, mode, chunk_tiles
+    c.si, c.sl, c.last, c.batch = si, sl, last, batch
+    c.tri_min_len, c.reserved = tri_min_len, 0
+    with torch.cuda.device(dev):
+        check(_lib.load().tmx_build_block_index(ctypes.byref(c), _ptr(cu_seqlens_q), _ptr(seq_lens),
+                                                cu_h.ctypes.data_as(ctypes.c_void_p),
+                                                sl_h.ctypes.data_as(ctypes.c_void_p), _stream(dev)))
+    return BlockIndex(row_ptr[:R + 1], col_idx[:nnz], qb_meta[:2 * R].view(R, 2) if R else qb_meta[:0].view(0, 2),
+                      part_ptr[:R + 1], items[:n_items], split_qb[:n_split], totals, scratch, sz, c, batch,
+                      block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len)
+
+
+# --------------------------------------------------------------------------- attention
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, index: BlockIndex,
+              cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, scale: float,
+              cu_seqlens_k: Optional[torch.Tensor] = None, block_table: Optional[torch.Tensor] = None,
+              bias: Optional[torch.Tensor] = None, workspace: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+    """Masked attention over the tiles ``index`` lists.
+
+    ``q``/``out``: ``[T, H, D]`` (last dim contiguous).  Contiguous K/V:
+    ``k``/``v`` ``[rows, Hkv, D]`` + ``cu_seqlens_k``.  Paged K/V: ``k``/``v``
+    ``[num_blocks, page_size, Hkv, D]`` + ``block_table`` ``[B, max_blocks]`` int32.
+    ``bias``: optional additive ``[rows >= max position + 1, cols >= max seq_len]``.
+    """
+    for t, name in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (cu_seqlens_q, "cu_seqlens_q"),
+                    (seq_lens, "seq_lens")):
+        _require_gpu(t, name)
+    if q.dim() != 3 or out.dim() != 3 or q.shape != out.shape:
+        raise RuntimeError("q and out must both be [T, H, D]")
+    if q.dtype not in (torch.bfloat16, torch.float16) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError("q, k, v must share a dtype of bfloat16 or float16")
+    if q.stride(2) != 1 or out.stride(2) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
+        raise RuntimeError("the head dimension must be contiguous")
+    if k.shape != v.shape or k.stride() != v.stride():
+        raise RuntimeError("k and v must have the same shape and strides")
+    T, H, D = q.shape
+    paged = block_table is not None
+    a = AttentionArgs()
+    a.struct_size = ctypes.sizeof(AttentionArgs)
+    a.io_dtype, a.out_dtype = dtype_code(q.dtype), dtype_code(out.dtype)
+    a.mode, a.si, a.sl, a.last, a.scale = index.mode, index.si, index.sl, index.last, float(scale)
+    a.batch, a.num_heads, a.head_dim, a.total_q = index.batch, H, D, T
+    a.out, a.out_stride_t, a.out_stride_h = out.data_ptr(), out.stride(0), out.stride(1)
+    a.q, a.q_stride_t, a.q_stride_h = q.data_ptr(), q.stride(0), q.stride(1)
+    a.k, a.v = k.data_ptr(), v.data_ptr()
+    if paged:
+        _require_gpu(block_table, "block_table")
+        if k.dim() != 4 or block_table.dim() != 2 or block_table.dtype != torch.int32:
+            raise RuntimeError("paged K/V: cache [num_blocks, page_size, Hkv, D], int32 block_table [B, max_blocks]")
+        a.num_kv_heads = k.shape[2]
+        a.kv_stride_page, a.kv_stride_t, a.kv_stride_h = k.stride(0), k.stride(1), k.stride(2)
+        a.block_table, a.block_table_stride, a.page_size = block_table.data_ptr(), block_table.stride(0), k.shape[1]
+        if block_table.stride(1) != 1 or block_table.shape[0] < index.batch:
+            raise RuntimeError("block_table rows must be contiguous and cover the batch")
+        a.cu_seqlens_k = None
+    else:
+        if cu_seqlens_k is None or k.dim() != 3:
+            raise RuntimeError("contiguous K/V: k/v [rows, Hkv, D] and cu_seqlens_k are required")
+        _require_gpu(cu_seqlens_k, "cu_seqlens_k")
+        a.num_kv_heads = k.shape[1]
+        a.kv_stride_page, a.kv_stride_t, a.kv_stride_h = 0, k.stride(0), k.stride(1)
+        a.block_table, a.block_table_stride, a.page_size = None, 0, 0
+        a.cu_seqlens_k = cu_seqlens_k.data_ptr()
+    if k.shape[-1] != D:
+        raise RuntimeError("k/v head size differs from q")
+    a.cu_seqlens_q, a.seq_lens = cu_seqlens_q.data_ptr(), seq_lens.data_ptr()
+    if bias is not None:
+        _require_gpu(bias, "bias")
+        if bias.dim() != 2 or bias.stride(1) != 1:
+            raise RuntimeError("bias must be 2-D with contiguous rows")
+        a.bias, a.bias_dtype, a.bias_stride = bias.data_ptr(), dtype_code(bias.dtype), bias.stride(0)
+        a.bias_rows, a.bias_cols = bias.shape
+    else:
+        a.bias, a.bias_dtype, a.bias_stride, a.bias_rows, a.bias_cols = None, 0, 0, 0, 0
+    a.index = ctypes.pointer(index.c)
+    sz = index.sizes
+    a.num_items, a.num_partials, a.num_split_qblocks = sz.num_items, sz.num_partials, sz.num_split_qblocks
+    part_o = part_ml = None
+    if sz.num_partials > 0:
+        if workspace is not None:
+            part_o, part_ml = workspace
+        else:
+            part_o, part_ml = alloc_workspace(index, H, D, q.device)
+        need = int(sz.num_partials) * H * index.block_m
+        if part_o.numel() < need * D or part_ml.numel() < need * 2 or part_o.dtype != torch.float32:
+            raise RuntimeError("attention workspace too small for this index")
+    a.partial_o, a.partial_ml = _ptr(part_o), _ptr(part_ml)
+    with torch.cuda.device(q.device):
+        check(_lib.load().tmx_attention(ctypes.byref(a), _stream(q.device)))
+    return out
+
+
+def alloc_workspace(index: BlockIndex, num_heads: int, head_dim: int, device):
+    """Partial-result buffers for the q-blocks the index splits."""
+    n = max(1, int(index.sizes.num_partials) * num_heads * index.block_m)
+    return (torch.empty((n * head_dim,), dtype=torch.float32, device=device),
+            torch.empty((n * 2,), dtype=torch.float32, device=device))
+
+
+# --------------------------------------------------------------------------- KV cache
+def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                      slot_mapping: torch.Tensor) -> None:
+    """Write this step's K/V rows into the paged cache (contract of the
+    reference's reshape_and_cache_flash, rocm_attn.py:345-354)."""
+    for t, name in ((key, "key"), (value, "value"), (key_cache, "key_cache"), (value_cache, "value_cache"),
+                    (slot_mapping, "slot_mapping")):
+        _require_gpu(t, name)
+    if slot_mapping.dtype != torch.int64 or not slot_mapping.is_contiguous():
+        raise RuntimeError("slot_mapping must be contiguous int64")
+    if key.shape != value.shape or key.stride() != value.stride() or key.dim() != 3:
+        raise RuntimeError("key and value must be [T, Hkv, D] with equal strides")
+    if key_cache.shape != value_cache.shape or key_cache.stride() != value_cache.stride() or key_cache.dim() != 4:
+        raise RuntimeError("caches must be [num_blocks, page_size, Hkv, D] with equal strides")
+    if key_cache.dtype != key.dtype:
+        raise RuntimeError("cache dtype must equal the key dtype (16-bit caches)")
+    n_tok = min(int(slot_mapping.numel()), key.shape[0])
+    with torch.cuda.device(key.device):
+        check(_lib.load().tmx_reshape_and_cache(
+            _ptr(key), _ptr(value), key.stride(0), key.stride(1), _ptr(key_cache), _ptr(value_cache),
+            key_cache.stride(0), key_cache.stride(1), key_cache.stride(2), _ptr(slot_mapping), n_tok,
+            key.shape[1], key.shape[2], key_cache.shape[1], dtype_code(key.dtype), _stream(key.device)))
