@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Benchmark of the TriangleMix hot path on MI355X.
+
+One step = one pass of the hot path over one batch of synthetic input:
+the packed block-sparse index is built on the device and the masked
+(triangle) attention of one Qwen3-8B layer runs over the whole prompt
+(prefill, paged K/V cache, page size 16, shuffled block table).
+
+N = 1: one 32768-token prompt, 32 query heads / 8 K/V heads / head dim 128.
+N > 1 (launched by torch.distributed.run, one rank per GPU): head-parallel
+tensor parallelism -- rank r owns 32/N query heads and 8/N K/V heads -- with
+the global batch grown to N prompts, so each rank keeps the same number of
+(prompt, head) units (weak scaling).  The attention needs no collective; the
+output projection's all-reduce (the only exchange step of the layer) is timed
+separately with --oproj and reported beside the main value, never inside it.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+QWEN3_8B = dict(num_heads=32, num_kv_heads=8, head_dim=128, hidden=4096)
+PATTERN = (4, 32, 64)  # sink, window, last: the reference defaults
+PAGE = 16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--seq-len", type=int, default=32768)
+    ap.add_argument("--oproj", action="store_true", help="also time o_proj GEMM + all-reduce (reported separately)")
+    ap.add_argument("--no-baselines", action="store_true", help="skip the dense and CPU baselines")
+    ap.add_argument("--cpu-rows", type=int, default=1024, help="query rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-heads", type=int, default=2, help="heads of the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def make_inputs(ops, dev, n, batch, heads, kv_heads, dim, seed):
+    """q [batch*n, heads, dim] bf16, paged K/V cache filled through the cache-write kernel."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    T = batch * n
+    q = torch.randn((T, heads, dim), generator=g, dtype=torch.float32).to(dev).bfloat16()
+    k = torch.randn((T, kv_heads, dim), generator=g, dtype=torch.float32).to(dev).bfloat16()
+    v = torch.randn((T, kv_heads, dim), generator=g, dtype=torch.float32).to(dev).bfloat16()
+    pages_per_seq = (n + PAGE - 1) // PAGE
+    nblk = batch * pages_per_seq
+    perm = torch.randperm(nblk, generator=g).to(torch.int32)
+    block_table = perm.view(batch, pages_per_seq).contiguous()
+    pos = torch.arange(n, dtype=torch.int64)
+    slots = torch.cat([block_table[b].to(torch.int64)[pos // PAGE] * PAGE + pos % PAGE for b in range(batch)])
+    kv_cache = torch.zeros((2, nblk, PAGE, kv_heads, dim), dtype=torch.bfloat16, device=dev)
+    ops.reshape_and_cache(k, v, kv_cache[0], kv_cache[1], slots.to(dev))
+    cu_h = (np.arange(batch + 1) * n).astype(np.int32)
+    sl_h = np.full((batch,), n, np.int32)
+    return dict(q=q, k=k, v=v, kv_cache=kv_cache, block_table=block_table.to(dev), cu_h=cu_h, sl_h=sl_h,
+                cu=torch.from_numpy(cu_h).to(dev), sl=torch.from_numpy(sl_h).to(dev))
+
+
+def cpu_baseline(n, heads, dim, rows, sample_heads):
+    """Times the C restatement of the reference's CPU path (mask loops + dense
+    eager attention) on a bounded sample: `rows` query rows spread evenly over
+    the n-token prompt, all n keys, `sample_heads` heads; scaled to all rows
+    and heads.  Baseline only."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libtmx_oracle.so"))
+    fp = ctypes.POINTER(ctypes.c_float)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    rng = np.random.default_rng(0)
+    step = max(1, n // rows)
+    rows = min(rows, n)
+    row0 = n - 1 - (rows - 1) * step  # includes the last row
+    k = rng.standard_normal((n, sample_heads, dim), dtype=np.float32)
+    v = rng.standard_normal((n, sample_heads, dim), dtype=np.float32)
+    q = rng.standard_normal((rows, sample_heads, dim), dtype=np.float32)
+    mask = np.empty((rows, n), np.float32)
+    out = np.empty_like(q)
+    t0 = time.perf_counter()
+    lib.tmx_oracle_triangle_additive_rows(mask.ctypes.data_as(fp), n, *PATTERN, row0, step, rows)
+    t_mask = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rc = lib.tmx_oracle_eager_attention_rows(q.ctypes.data_as(fp), k.ctypes.data_as(fp), v.ctypes.data_as(fp),
+                                             mask.ctypes.data_as(fp), out.ctypes.data_as(fp), rows, n, sample_heads,
+                                             dim, ctypes.c_float(dim ** -0.5))
+    t_attn = time.perf_counter() - t0
+    assert rc == 0 and np.isfinite(out).all()
+    # whole job: the mask is built once (all n rows), the attention runs for all rows and heads
+    t_full = t_mask * (n / rows) + t_attn * (n / rows) * (heads / sample_heads)
+    return {"value": n / t_full, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{rows} of {n} query rows (every {step}th, incl. the last) x all {n} keys x {sample_heads} of "
+                      f"{heads} heads, fp32, mask loops {t_mask:.2f}s + dense attention {t_attn:.2f}s, scaled to "
+                      f"all rows and heads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the TriangleMix path has no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from vllm_trianglemix_amd import ops
+    from vllm_trianglemix_amd._lib import TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SKIP_COMBINE
+    from vllm_trianglemix_amd.parallel import RowParallelOutputProjection, shard_heads
+
+    n = args.seq_len
+    shard = shard_heads(QWEN3_8B["num_heads"], QWEN3_8B["num_kv_heads"], rank, world)
+    H, Hkv, D = shard.num_heads, shard.num_kv_heads, QWEN3_8B["head_dim"]
+    batch = world  # weak scaling: one more prompt per GPU
+    inp = make_inputs(ops, dev, n, batch, H, Hkv, D, seed=0)  # same prompts on every rank, different head shards
+    si, sl, last = PATTERN
+    bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
+    scale = D ** -0.5
+    out = torch.empty_like(inp["q"])
+    kc, vc = inp["kv_cache"][0], inp["kv_cache"][1]
+
+    def build(mode):
+        return ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn,
+                                     ops.MODES[mode])
+
+    idx0 = build("triangle")
+    work = ops.alloc_workspace(idx0, H, D, dev)
+
+    def step():
+        idx = build("triangle")
+        ops.attention(inp["q"], kc, vc, out, idx, inp["cu"], inp["sl"], scale, block_table=inp["block_table"],
+                      workspace=work)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    tokens_per_step = batch * n  # whole job: every prompt is processed once per step (heads are split over ranks)
+    value = tokens_per_step / (elapsed / args.steps)
+
+    # ---- dominant kernel alone, timed with events on the launch stream ----
+    def timed(fn, iters):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize(dev)
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))  # ms
+
+    def attn_only():
+        ops.attention(inp["q"], kc, vc, out, idx0, inp["cu"], inp["sl"], scale, block_table=inp["block_table"],
+                      workspace=work, flags=TMX_ATTN_SKIP_COMBINE)
+
+    def combine_only():
+        ops.attention(inp["q"], kc, vc, out, idx0, inp["cu"], inp["sl"], scale, block_table=inp["block_table"],
+                      workspace=work, flags=TMX_ATTN_ONLY_COMBINE)
+
+    iters = max(5, min(args.steps, 50))
+    for _ in range(3):
+        attn_only()
+    t_attn_ms = timed(attn_only, iters)
+    t_comb_ms = timed(combine_only, iters)
+    t_index_ms = timed(lambda: build("triangle"), iters)
+    # algorithmic bytes per token per attention call: Q read + O write + K read + V read, 16-bit elements
+    bytes_per_token = 2 * (H + Hkv) * D * 2
+    algo_bytes = bytes_per_token * batch * n
+    achieved = algo_bytes / (t_attn_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and world == 1:
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("seq_len") == n and tj.get("kernel") == "attn_kernel":
+            traffic = tj.get("hbm_bytes_per_launch")
+    roofline = {"bound": "hbm", "kernel": "attn_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel_ms": t_attn_ms, "combine_ms": t_comb_ms, "index_build_ms": t_index_ms}
+
+    extra = {}
+    if not args.no_baselines and rank == 0:
+        # dense-causal baselines at the same shape (attention-op level)
+        try:
+            idx_c = build("causal")
+            work_c = ops.alloc_workspace(idx_c, H, D, dev)
+
+            def dense_own():
+                ops.attention(inp["q"], kc, vc, out, idx_c, inp["cu"], inp["sl"], scale,
+                              block_table=inp["block_table"], workspace=work_c)
+
+            dense_own()
+            t_dense = timed(dense_own, 3)
+            extra["dense_causal_own_kernel_tokens_per_s"] = batch * n / (t_dense * 1e-3)
+            extra["speedup_vs_own_dense"] = t_dense / (ms_per_step)
+            del work_c
+        except Exception as e:  # pragma: no cover
+            extra["dense_causal_own_kernel_error"] = repr(e)
+        try:
+            import torch.nn.functional as F
+            qs = inp["q"][:n].transpose(0, 1).unsqueeze(0)
+            ks = inp["k"][:n].transpose(0, 1).unsqueeze(0)
+            vs = inp["v"][:n].transpose(0, 1).unsqueeze(0)
+
+            def sdpa():
+                return F.scaled_dot_product_attention(qs, ks, vs, is_causal=True, enable_gqa=True)
+
+            sdpa()
+            t_sdpa = timed(sdpa, 3)
+            extra["dense_causal_torch_sdpa_tokens_per_s"] = n / (t_sdpa * 1e-3)
+            extra["speedup_vs_torch_sdpa"] = (t_sdpa * batch) / ms_per_step
+        except Exception as e:  # pragma: no cover
+            extra["dense_causal_torch_sdpa_error"] = repr(e)[:200]
+
+    if args.oproj:
+        hidden = QWEN3_8B["hidden"]
+        w = (torch.randn((hidden, H * D), device=dev) * 0.02).bfloat16()
+        proj = RowParallelOutputProjection(w, chunk_tokens=8192 if world > 1 else 0)
+        proj(out)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            proj(out)
+        sync_all()
+        extra["oproj_gemm_allreduce_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+
+    cpu = None
+    if not args.no_baselines and rank == 0 and world == 1:
+        cpu = cpu_baseline(n, QWEN3_8B["num_heads"], D, args.cpu_rows, args.cpu_heads)
+
+    if rank == 0:
+        line = {
+            "metric": "prefill tokens/sec (TriangleMix attention op, index build included), Qwen3-8B 32k ctx",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Qwen3-8B bf16 seq_len={n} TriangleMix prefill (one attention layer: block-index "
+                                   f"build + masked attention), sink/window/last={PATTERN}, paged KV page {PAGE}",
+                       "global_batch": batch, "seq_len": n, "heads_per_gpu": H, "kv_heads_per_gpu": Hkv,
+                       "head_dim": D, "parallelism": f"tp{world} (heads)" if world > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

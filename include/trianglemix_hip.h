@@ -205,7 +205,16 @@ typedef struct tmx_attention_args_t {
    * May be NULL when num_partials == 0. */
   float* partial_o;
   float* partial_ml;
+
+  /* Measurement aids (0 in normal use): TMX_ATTN_SKIP_COMBINE leaves split
+   * q-blocks as partials, TMX_ATTN_ONLY_COMBINE runs the merge pass alone, so
+   * that each kernel can be timed on its own with stream events. */
+  uint32_t flags;
+  uint32_t reserved;
 } tmx_attention_args_t;
+
+#define TMX_ATTN_SKIP_COMBINE 1u
+#define TMX_ATTN_ONLY_COMBINE 2u
 
 int tmx_attention(const tmx_attention_args_t* args, void* stream);
 

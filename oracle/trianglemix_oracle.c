@@ -105,10 +105,69 @@ int tmx_oracle_eager_attention(const float* q, const float* k, const float* v, c
         for (int d = 0; d < D; ++d) oi[d] = 0.f;
         for (int j = 0; j < N; ++j) {
           float p = s[j] / den;
-          if (p == 0.f) continue;
           const float* vj = v + (((size_t)b * N + j) * H + h) * D;
           for (int d = 0; d < D; ++d) oi[d] += p * vj[d];
         }
+      }
+      free(s);
+    }
+  return rc;
+}
+
+/*
+ * Row-range forms of the same loops, for timing a bounded sample of a large
+ * problem: rows row0, row0 + row_step, ... (nrows of them) of the length-n
+ * problem.  Identical arithmetic per row to the full-size functions above.
+ */
+void tmx_oracle_triangle_additive_rows(float* out, int n, int si, int sl, int last, int row0, int row_step,
+                                       int nrows) {
+  for (int r = 0; r < nrows; ++r) {
+    const int i = row0 + r * row_step;
+    float* o = out + (size_t)r * n;
+    /* streaming pass, last pass, add + clamp, then 0 / -inf: trianglemix_attention.py:82-89,126-129,192-196,254-258 */
+    for (int j = 0; j < n; ++j) {
+      float v = 0.f;
+      if (i >= j && j <= si) v = 1.f;
+      else if (i >= j && (i - j) <= sl) v = 1.f;
+      o[j] = v;
+    }
+    for (int j = 0; j < n; ++j) {
+      float l = (i >= j && (n - i) < last && j > si && (i - j) > sl) ? 1.f : 0.f;
+      float t = o[j] + l;
+      t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+      o[j] = (t > 0.f) ? 0.f : -INFINITY;
+    }
+  }
+}
+
+/* q_rows: [nrows, H, D] (the sampled query rows), k / v: [n, H, D], mask_rows: [nrows, n] additive or NULL. */
+int tmx_oracle_eager_attention_rows(const float* q_rows, const float* k, const float* v, const float* mask_rows,
+                                    float* out_rows, int nrows, int n, int H, int D, float scale) {
+  int rc = 0;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int h = 0; h < H; ++h)
+    for (int r = 0; r < nrows; ++r) {
+      float* s = (float*)malloc((size_t)n * sizeof(float));
+      if (!s) { rc = -1; continue; }
+      const float* qi = q_rows + ((size_t)r * H + h) * D;
+      float mx = -INFINITY;
+      for (int j = 0; j < n; ++j) {
+        const float* kj = k + ((size_t)j * H + h) * D;
+        float acc = 0.f;
+        for (int d = 0; d < D; ++d) acc += qi[d] * kj[d];
+        acc *= scale;
+        if (mask_rows) acc += mask_rows[(size_t)r * n + j];
+        s[j] = acc;
+        if (acc > mx) mx = acc;
+      }
+      float den = 0.f;
+      for (int j = 0; j < n; ++j) { s[j] = expf(s[j] - mx); den += s[j]; }
+      float* oi = out_rows + ((size_t)r * H + h) * D;
+      for (int d = 0; d < D; ++d) oi[d] = 0.f;
+      for (int j = 0; j < n; ++j) {
+        float p = s[j] / den;
+        const float* vj = v + ((size_t)j * H + h) * D;
+        for (int d = 0; d < D; ++d) oi[d] += p * vj[d];
       }
       free(s);
     }

@@ -62,7 +62,10 @@ class AttentionArgs(Structure):
         ("index", POINTER(Index)),
         ("num_items", c_int64), ("num_partials", c_int64), ("num_split_qblocks", c_int64),
         ("partial_o", c_void_p), ("partial_ml", c_void_p),
+        ("flags", c_uint32), ("reserved", c_uint32),
     ]
+
+TMX_ATTN_SKIP_COMBINE, TMX_ATTN_ONLY_COMBINE = 1, 2
 
 
 _lib = None

@@ -420,8 +420,9 @@ __global__ __launch_bounds__(256) void combine_kernel(AttnParams p) {
 }
 
 template <typename TR, int D>
-static int launch(const AttnParams& p, bool paged, bool has_bias, dim3 grid, int64_t num_split, hipStream_t s) {
-  if (grid.x > 0) {
+static int launch(const AttnParams& p, bool paged, bool has_bias, dim3 grid, int64_t num_split, uint32_t flags,
+                  hipStream_t s) {
+  if (grid.x > 0 && !(flags & TMX_ATTN_ONLY_COMBINE)) {
     if (paged) {
       if (has_bias) attn_kernel<TR, D, true, true><<<grid, 256, 0, s>>>(p);
       else attn_kernel<TR, D, true, false><<<grid, 256, 0, s>>>(p);
@@ -431,7 +432,7 @@ static int launch(const AttnParams& p, bool paged, bool has_bias, dim3 grid, int
     }
     TMX_CHECK_HIP(hipGetLastError());
   }
-  if (num_split > 0) {
+  if (num_split > 0 && !(flags & TMX_ATTN_SKIP_COMBINE)) {
     combine_kernel<TR, D><<<dim3((unsigned)num_split, (unsigned)p.H), 256, 0, s>>>(p);
     TMX_CHECK_HIP(hipGetLastError());
   }
@@ -541,9 +542,9 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   TMX_CHECK_ARG(grid.y <= 65535, "tmx_attention: too many K/V head chunks (%u)", grid.y);
   hipStream_t s = (hipStream_t)stream;
   if (a->io_dtype == TMX_BF16) {
-    if (a->head_dim == 128) return launch<Bf16Traits, 128>(p, paged, has_bias, grid, a->num_split_qblocks, s);
-    return launch<Bf16Traits, 64>(p, paged, has_bias, grid, a->num_split_qblocks, s);
+    if (a->head_dim == 128) return launch<Bf16Traits, 128>(p, paged, has_bias, grid, a->num_split_qblocks, a->flags, s);
+    return launch<Bf16Traits, 64>(p, paged, has_bias, grid, a->num_split_qblocks, a->flags, s);
   }
-  if (a->head_dim == 128) return launch<F16Traits, 128>(p, paged, has_bias, grid, a->num_split_qblocks, s);
-  return launch<F16Traits, 64>(p, paged, has_bias, grid, a->num_split_qblocks, s);
+  if (a->head_dim == 128) return launch<F16Traits, 128>(p, paged, has_bias, grid, a->num_split_qblocks, a->flags, s);
+  return launch<F16Traits, 64>(p, paged, has_bias, grid, a->num_split_qblocks, a->flags, s);
 }

@@ -179,7 +179,8 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, index: BlockIndex,
               cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, scale: float,
               cu_seqlens_k: Optional[torch.Tensor] = None, block_table: Optional[torch.Tensor] = None,
-              bias: Optional[torch.Tensor] = None, workspace: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+              bias: Optional[torch.Tensor] = None, workspace: Optional[Sequence[torch.Tensor]] = None,
+              flags: int = 0) -> torch.Tensor:
     """Masked attention over the tiles ``index`` lists.
 
     ``q``/``out``: ``[T, H, D]`` (last dim contiguous).  Contiguous K/V:
@@ -250,6 +251,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
         if part_o.numel() < need * D or part_ml.numel() < need * 2 or part_o.dtype != torch.float32:
             raise RuntimeError("attention workspace too small for this index")
     a.partial_o, a.partial_ml = _ptr(part_o), _ptr(part_ml)
+    a.flags, a.reserved = int(flags), 0
     with torch.cuda.device(q.device):
         check(_lib.load().tmx_attention(ctypes.byref(a), _stream(q.device)))
     return out
