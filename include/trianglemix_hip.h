@@ -97,7 +97,8 @@ int tmx_replace_neg_inf(void* mask_dev, int64_t count, int dtype, float value, v
  * plus per q-block metadata and a work list for the attention kernel:
  *     qb_meta[R][2]    = (request b, first row offset inside the request)
  *     part_ptr[R + 1]  = first partial slot of each q-block (see below)
- *     items[I][4]      = (q-block, first entry in col_idx, tile count, partial slot)
+ *     items[I][8]      = (q-block, first entry in col_idx, tile count, partial slot,
+ *                         request b, first row in the packed q tensor, position of that row, seq_len)
  *     split_qb[S]      = the q-blocks whose tile list was split, ascending
  * A q-block with more than chunk_tiles tiles is split into pieces of at most
  * chunk_tiles tiles; each piece is one item with its own partial slot, merged
@@ -127,7 +128,7 @@ typedef struct tmx_index_t {
   int32_t* col_idx;   /* [nnz] */
   int32_t* qb_meta;   /* [R][2] */
   int32_t* part_ptr;  /* [R + 1] */
-  int32_t* items;     /* [I][4] */
+  int32_t* items;     /* [I][8], 16-byte aligned */
   int32_t* split_qb;  /* [S] (may be NULL when S == 0) */
   int32_t* totals;    /* [8]: R, nnz, I, partials, S, max tiles per q-block, 0, 0 -- as the kernel counted them */
   int32_t* scratch;   /* [batch + 1 + 2 * (R + 1)] work area of the scan */

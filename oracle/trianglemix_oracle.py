@@ -384,7 +384,7 @@ def block_index_closed_form(q_lens, seq_lens, si, sl, last, bm, bn, mode):
             np.asarray(qb_seq, np.int32), np.asarray(qb_row0, np.int32))
 
 
-def work_items(row_ptr: np.ndarray, chunk: int):
+def work_items(row_ptr: np.ndarray, chunk: int, qb_seq=None, qb_row0=None, q_lens=None, seq_lens=None):
     """Split every q-block's tile list into pieces of at most ``chunk`` tiles.
 
     Items are listed for q-blocks in DESCENDING order (the heavy trailing
@@ -395,6 +395,10 @@ def work_items(row_ptr: np.ndarray, chunk: int):
     dense running number over all pieces that need the combine pass, counted
     in q-block ASCENDING order.  Also returns ``part_ptr[int32, R+1]``: the
     first partial slot of each q-block (equal consecutive values = no split).
+
+    When the q-block geometry is given, four more columns are appended per
+    item: ``(request, first row of the q-block in the packed q tensor, position
+    of that row in its sequence, seq_len)``.
     """
     r = len(row_ptr) - 1
     cnt = np.diff(row_ptr.astype(np.int64))
@@ -408,8 +412,15 @@ def work_items(row_ptr: np.ndarray, chunk: int):
             start = int(row_ptr[qb]) + p * chunk
             ntile = int(min(chunk, int(row_ptr[qb + 1]) - start))
             slot = int(part_ptr[qb]) + p if npieces[qb] > 1 else -1
-            items.append((qb, start, max(ntile, 0), slot))
-    return np.asarray(items, np.int32).reshape(-1, 4), part_ptr.astype(np.int32)
+            rec = (qb, start, max(ntile, 0), slot)
+            if qb_seq is not None:
+                b = int(qb_seq[qb])
+                cu = int(np.sum(q_lens[:b]))
+                rec += (b, cu + int(qb_row0[qb]), int(seq_lens[b]) - int(q_lens[b]) + int(qb_row0[qb]),
+                        int(seq_lens[b]))
+            items.append(rec)
+    width = 4 if qb_seq is None else 8
+    return np.asarray(items, np.int32).reshape(-1, width), part_ptr.astype(np.int32)
 
 
 def expand_index_to_mask(row_ptr, col_idx, qb_seq, qb_row0, q_lens, seq_lens, si, sl, last, bm, bn, mode):

@@ -119,7 +119,7 @@ def _build(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk=4, gate=0):
 def _check_index(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk):
     idx, _, _ = _build(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk)
     row_ptr, col_idx, qb_seq, qb_row0 = orc.block_index_closed_form(q_lens, seq_lens, si, sl, last, bm, bn, mode)
-    items, part_ptr = orc.work_items(row_ptr, chunk)
+    items, part_ptr = orc.work_items(row_ptr, chunk, qb_seq, qb_row0, q_lens, seq_lens)
     tot = idx.totals.cpu().numpy()
     assert tot[0] == len(row_ptr) - 1 == idx.sizes.num_qblocks
     assert tot[1] == len(col_idx) == idx.sizes.nnz_tiles

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Runs a few attention launches of one configuration (for rocprofv3 --pmc / --kernel-trace).
+Usage: python tools/run_once.py MODE N [ITERS] [CHUNK]   (MODE: triangle|causal|stream|window)"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vllm_trianglemix_amd import ops
+from vllm_trianglemix_amd._lib import TMX_ATTN_SKIP_COMBINE
+mode = sys.argv[1]; n = int(sys.argv[2]); iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+H, Hkv, D = 32, 8, 128
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+q = torch.randn((n, H, D), generator=g).to(dev).bfloat16()
+k = torch.randn((n, Hkv, D), generator=g).to(dev).bfloat16()
+v = torch.randn((n, Hkv, D), generator=g).to(dev).bfloat16()
+out = torch.empty_like(q)
+cu_h, sl_h = np.asarray([0, n], np.int32), np.asarray([n], np.int32)
+cu, sl = torch.from_numpy(cu_h).to(dev), torch.from_numpy(sl_h).to(dev)
+pat = {"triangle": (4, 32, 64, "triangle"), "stream": (4, 32, 0, "triangle"), "window": (-1, 32, 0, "triangle"),
+       "causal": (0, 0, 0, "causal")}[mode]
+idx = ops.build_block_index(cu, sl, cu_h, sl_h, pat[0], pat[1], pat[2], ops.attention_block_m(H, Hkv), 32,
+                            ops.MODES[pat[3]], chunk_tiles=chunk)
+work = ops.alloc_workspace(idx, H, D, dev)
+for _ in range(iters):
+    ops.attention(q, k, v, out, idx, cu, sl, D ** -0.5, cu_seqlens_k=cu, workspace=work, flags=TMX_ATTN_SKIP_COMBINE)
+torch.cuda.synchronize()
+print("done", mode, n, idx.sizes.num_items)

@@ -31,6 +31,7 @@
 namespace tmx {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -88,27 +89,29 @@ struct AttnParams {
   float scale_log2;
 };
 
+// Read through the scalar (constant) path: the index, the block table and the
+// batch description are wave-uniform and never written while the kernel runs.
+template <typename T>
+__device__ __forceinline__ T sload(const T* ptr) {
+  return *reinterpret_cast<const __attribute__((address_space(4))) T*>(
+      (const __attribute__((address_space(4))) void*)ptr);
+}
+
 // 16-byte chunk swizzle of the K image: rows of D 16-bit elements, read by
 // ds_read_b128 with 16 different rows per lane group.
 template <int D>
-__device__ __forceinline__ int k_chunk_swizzle(int chunk, int row) {
-  if constexpr (D == 128) return chunk ^ (row & 15);
-  else return chunk ^ ((row >> 1) & 7);  // D == 64: two rows share a 256-byte bank row
+__device__ __forceinline__ int k_chunk_swizzle(int row) {
+  if constexpr (D == 128) return row & 15;
+  else return (row >> 1) & 7;  // D == 64: two rows share a 256-byte bank row
 }
 
-// 8-byte slot swizzle of the V image, read by ds_read_b64_tr_b16: the 32 lanes
-// of a half-wave read 8 key rows x 4 slots; the XOR spreads the 8 rows over the
-// slot bits the read pattern leaves free.
+// 16-byte chunk swizzle of the V image, read by ds_read_b64_tr_b16: the 32
+// lanes of a half-wave read 8 key rows x 32 contiguous bytes; the XOR moves
+// the 8 rows to 8 different 32-byte groups of the 256-byte bank row.
 template <int D>
-__device__ __forceinline__ int v_slot_xor(int row) {
-  if constexpr (D == 128) return (row & 1) | (((row >> 1) & 3) << 3);
-  else return ((row >> 1) & 1) | (((row >> 2) & 1) << 3);
-}
-
-// slot (8-byte unit) of output block db, chunk p of the transposed read
-template <int D>
-__device__ __forceinline__ constexpr int v_db_bits(int db) {
-  return 8 * (db >> 1) + (db & 1);
+__device__ __forceinline__ int v_chunk_swizzle(int row) {
+  if constexpr (D == 128) return (row & 7) << 1;
+  else return ((row >> 1) & 3) << 1;
 }
 
 __device__ __forceinline__ float load_bias(const void* bias, int dtype, int64_t off) {
@@ -117,29 +120,70 @@ __device__ __forceinline__ float load_bias(const void* bias, int dtype, int64_t 
   return dtype == TMX_BF16 ? Bf16Traits::to_float(b) : F16Traits::to_float(b);
 }
 
-template <typename TR, int D, bool PAGED, bool HAS_BIAS>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+// Wait until at most `tiles` of this wave's most recent tile transfers are
+// still in flight (DPT LDS-DMA instructions per tile and wave).
+template <int DPT, int MAXT>
+__device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+  if constexpr (MAXT >= 3) {
+    if (tiles >= 3) { wait_vmcnt<3 * DPT>(); return; }
+  }
+  if constexpr (MAXT >= 2) {
+    if (tiles == 2) { wait_vmcnt<2 * DPT>(); return; }
+  }
+  if constexpr (MAXT >= 1) {
+    if (tiles == 1) { wait_vmcnt<DPT>(); return; }
+  }
+  wait_vmcnt<0>();
+}
+
+// One LDS-DMA instruction: every lane fetches 16 bytes from its own global
+// address; the wave's 1 KiB lands at LDS byte address lds_addr + 16 * lane.
+// Issued from inline asm on purpose: the compiler would otherwise wait for ALL
+// transfers in flight (vmcnt(0)) before every LDS read; here the waits are
+// counted by hand (wait_tiles_in_flight) and followed by a workgroup barrier.
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_addr)
+      : "memory");
+}
+
+template <typename TR, int D, int NS, bool PAGED, bool HAS_BIAS>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
-  constexpr int KS = D / 32;          // k-steps of S^T = K Q^T
-  constexpr int DB = D / 16;          // 16-column output blocks
-  constexpr int ROWB = D * 2;         // bytes per K/V row in LDS
-  constexpr int CPR = D / 8;          // 16-byte chunks per row
-  constexpr int TILE = 32 * ROWB;     // bytes of one K (or V) tile
-  constexpr int LPT = 32 * CPR / 256; // 16-byte chunks each thread stages per tile and tensor
+  constexpr int KS = D / 32;            // k-steps of S^T = K Q^T
+  constexpr int DB = D / 16;            // 16-column output blocks
+  constexpr int ROWB = D * 2;           // bytes per K/V row in LDS
+  constexpr int CPR = D / 8;            // 16-byte chunks per row
+  constexpr int TILE = 32 * ROWB;       // bytes of one K (or V) tile
+  constexpr int RPP = 1024 / ROWB;      // rows per 1-KiB LDS-DMA piece (one wave instruction)
+  constexpr int U = TILE / 1024 / 4;    // pieces per wave, tile and tensor
+  constexpr int DPT = 2 * U;            // LDS-DMA instructions per wave and tile (K and V)
   using frag = typename TR::frag;
 
-  __shared__ __attribute__((aligned(16))) char lds[4 * TILE];  // [buffer][K | V]
+  __shared__ __attribute__((aligned(16))) char lds[NS * 2 * TILE];  // ring of [K | V] tile slots
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 15, g = lane >> 4;
 
-  const int4 item = reinterpret_cast<const int4*>(p.items)[blockIdx.x];
-  const int qb = item.x, col_start = item.y, ntiles = item.z, slot = item.w;
-  const int b = p.qb_meta[2 * qb], row0 = p.qb_meta[2 * qb + 1];
-  const int q_start = p.cu_q[b];
-  const int q_len = p.cu_q[b + 1] - q_start;
-  const int n = p.seq_lens[b];
-  const int ctx = n - q_len;
+  // ---- work item: 8 ints, read through the scalar path ----
+  const i32x4 it0 = sload(reinterpret_cast<const i32x4*>(p.items) + 2 * blockIdx.x);
+  const i32x4 it1 = sload(reinterpret_cast<const i32x4*>(p.items) + 2 * blockIdx.x + 1);
+  const int col_start = it0.y, ntiles = it0.z, slot = it0.w;
+  const int b = it1.x, q_tok0 = it1.y, pos0 = it1.z, n = it1.w;
+  const int rows_valid = imin(p.block_m, n - pos0);
   const int mode = effective_mode(p.mode, n, p.tri_min_len);
 
   const int chunks = p.G / p.Gw;
@@ -148,17 +192,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   const int hg = wave % p.Gw, rb = wave / p.Gw;
   const int head = kvh * p.G + hc * p.Gw + hg;
 
-  const int wrow0 = row0 + 16 * rb;                   // first row of this wave (inside the request)
-  const int wrow1 = imin(wrow0 + 16, q_len);          // one past its last valid row
-  const bool wave_has_rows = wrow0 < q_len;
+  const int wrow0 = 16 * rb;                           // first row of this wave inside the q-block
+  const int wrow1 = imin(wrow0 + 16, rows_valid);      // one past its last valid row
+  const bool wave_has_rows = wrow0 < rows_valid;
   const int my_row = wrow0 + qi;
-  const bool row_valid = my_row < q_len;
-  const int pos_i = ctx + my_row;
+  const bool row_valid = my_row < rows_valid;
+  const int pos_i = pos0 + my_row;
 
   // ---- Q fragments (B operand of S^T): 16 contiguous bytes per k-step ----
   frag qf[KS];
   {
-    const uint16_t* qp = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)(q_start + my_row) * p.q_stride_t +
+    const uint16_t* qp = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)(q_tok0 + my_row) * p.q_stride_t +
                          (int64_t)head * p.q_stride_h + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -168,48 +212,42 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     }
   }
 
-  // ---- K/V staging: global -> registers -> LDS ----
-  const int64_t k_row0 = PAGED ? 0 : (int64_t)p.cu_k[b];
+  // ---- K/V tiles: global -> LDS ring by LDS-DMA, NS - 1 tiles ahead ----
+  const int64_t k_row0 = PAGED ? 0 : (int64_t)sload(p.cu_k + b);
   const int32_t* bt = PAGED ? p.block_table + (int64_t)b * p.block_table_stride : nullptr;
   const uint16_t* kbase = reinterpret_cast<const uint16_t*>(p.k) + (int64_t)kvh * p.kv_stride_h;
   const uint16_t* vbase = reinterpret_cast<const uint16_t*>(p.v) + (int64_t)kvh * p.kv_stride_h;
-  uint4 kreg[LPT], vreg[LPT];
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds));
+  const int last_key = n - 1;
+  const int last_page = PAGED ? (last_key >> p.page_shift) : 0;
 
-  auto issue_loads = [&](int tile) {
-#pragma unroll
-    for (int u = 0; u < LPT; ++u) {
-      const int c = tid + 256 * u;
-      const int row = c / CPR, cc = c % CPR;
-      const int j = tile * kBlockN + row;
-      kreg[u] = make_uint4(0, 0, 0, 0);
-      vreg[u] = make_uint4(0, 0, 0, 0);
-      if (j < n) {
-        int64_t off;
-        if constexpr (PAGED) {
-          const int pg = p.page_shift >= 0 ? (j >> p.page_shift) : (j / p.page_size);
-          const int in_pg = j - pg * p.page_size;
-          off = (int64_t)bt[pg] * p.kv_stride_page + (int64_t)in_pg * p.kv_stride_t;
-        } else {
-          off = (k_row0 + j) * p.kv_stride_t;
-        }
-        off += cc * 8;
-        kreg[u] = *reinterpret_cast<const uint4*>(kbase + off);
-        vreg[u] = *reinterpret_cast<const uint4*>(vbase + off);
-      }
+  auto issue_tile = [&](int tile, int ring_slot) {
+    const unsigned kdst = lds_base + ring_slot * 2 * TILE;
+    const unsigned vdst = kdst + TILE;
+    int64_t pg_off0 = 0, pg_off1 = 0;
+    int pg_first = 0;
+    if constexpr (PAGED) {
+      pg_first = (tile * kBlockN) >> p.page_shift;
+      pg_off0 = (int64_t)sload(bt + pg_first) * p.kv_stride_page;
+      pg_off1 = (int64_t)sload(bt + imin(pg_first + 1, last_page)) * p.kv_stride_page;
     }
-  };
-  auto write_lds = [&](int buf) {
-    char* kb_ = lds + buf * 2 * TILE;
-    char* vb_ = kb_ + TILE;
 #pragma unroll
-    for (int u = 0; u < LPT; ++u) {
-      const int c = tid + 256 * u;
-      const int row = c / CPR, cc = c % CPR;
-      *reinterpret_cast<uint4*>(kb_ + row * ROWB + 16 * k_chunk_swizzle<D>(cc, row)) = kreg[u];
-      const int x = v_slot_xor<D>(row);
-      uint4 w = vreg[u];
-      if (x & 1) w = make_uint4(w.z, w.w, w.x, w.y);
-      *reinterpret_cast<uint4*>(vb_ + row * ROWB + 8 * (((2 * cc) ^ x) & ~1)) = w;
+    for (int u = 0; u < U; ++u) {
+      const int piece = wave * U + u;
+      const int row = piece * RPP + lane / CPR;
+      const int cc = lane % CPR;
+      // keys past the end of the sequence are masked later; clamp their source to a valid row
+      const int j = imin(tile * kBlockN + row, last_key);
+      int64_t off;
+      if constexpr (PAGED) {
+        const int pg = j >> p.page_shift;
+        off = (pg == pg_first ? pg_off0 : pg_off1) + (int64_t)(j & (p.page_size - 1)) * p.kv_stride_t;
+      } else {
+        off = (k_row0 + j) * p.kv_stride_t;
+      }
+      glds16(kbase + off + 8 * (cc ^ k_chunk_swizzle<D>(row)), kdst + piece * 1024);
+      glds16(vbase + off + 8 * (cc ^ v_chunk_swizzle<D>(row)), vdst + piece * 1024);
     }
   };
 
@@ -217,13 +255,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   // K: row 16*kb + qi, chunk 4*ks + g (swizzled)
   int k_off[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) k_off[ks] = qi * ROWB + 16 * k_chunk_swizzle<D>(4 * ks + g, qi);
+  for (int ks = 0; ks < KS; ++ks) k_off[ks] = qi * ROWB + 16 * ((4 * ks + g) ^ k_chunk_swizzle<D>(qi));
   // V transposed read: lane 4*q' + pp of each 16-lane group addresses key row 4*g + q' (+16 for the
-  // second half of the tile), slot 2*pp + (bits of the output block)
+  // second half of the tile), columns 16*db + 4*pp .. +3
   const int vq = (lane & 15) >> 2, vp = lane & 3;
   const int v_row = 4 * g + vq;
-  const int v_x = v_slot_xor<D>(v_row);  // identical for row and row + 16
-  const int v_base = v_row * ROWB + 8 * (2 * vp);
+  const int v_x = v_chunk_swizzle<D>(v_row) >> 1;  // XOR on the 32-byte group index == the output block db
+  const int v_base = v_row * ROWB + 8 * vp;
 
   f32x4 acc[DB];
 #pragma unroll
@@ -231,30 +269,61 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   float m_run = -__builtin_inff();
   float l_run = 0.f;
 
-  const int i_min = ctx + wrow0, i_max = ctx + wrow1 - 1;  // positions of this wave's rows
-
-  if (ntiles > 0) {
-    issue_loads(p.col_idx[col_start]);
-    write_lds(0);
+  const int i_min = pos0 + wrow0, i_max = pos0 + wrow1 - 1;  // positions of this wave's rows
+  const bool wave_any_last = (n - i_max) < p.last;           // some row is in the dense trailing region
+  const bool wave_all_last = (n - i_min) < p.last;           // every row is
+  // per-lane form of the predicate: attended iff j <= key_hi and not (hole_lo < j < hole_lo + 1 + hole_width)
+  int key_hi = -1;
+  int hole_lo = 0;
+  unsigned hole_width = 0;
+  if (row_valid) {
+    key_hi = (mode == TMX_MODE_NONE) ? n - 1 : imin(pos_i, n - 1);
+    if (mode == TMX_MODE_TRIANGLE && !((n - pos_i) < p.last)) {
+      // keys si < j < pos_i - sl are the excluded middle section
+      hole_lo = p.si;
+      const long long w = (long long)pos_i - p.sl - (long long)p.si - 1;
+      hole_width = w > 0 ? (unsigned)w : 0u;
+      if (p.si < -1) {  // a negative sink size excludes nothing below key 0; start the hole at -1
+        hole_lo = -1;
+        const long long w2 = (long long)pos_i - p.sl;
+        hole_width = w2 > 0 ? (unsigned)w2 : 0u;
+      }
+    }
   }
-  __syncthreads();
+
+  int issued = 0;
+  for (; issued < ntiles && issued < NS - 1; ++issued) issue_tile(sload(p.col_idx + col_start + issued), issued);
+  // Settle the Q registers here, once: a first use inside the loop would make the compiler wait for
+  // every transfer in flight on each iteration.
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
 
   for (int t = 0; t < ntiles; ++t) {
-    const int tile = p.col_idx[col_start + t];
-    const bool more = t + 1 < ntiles;
-    if (more) issue_loads(p.col_idx[col_start + t + 1]);
+    const int tile = sload(p.col_idx + col_start + t);
+    wait_tiles_in_flight<DPT, NS - 2>(issued - 1 - t);
+    __builtin_amdgcn_s_barrier();
+    if (issued < ntiles) {
+      issue_tile(sload(p.col_idx + col_start + issued), issued % NS);
+      ++issued;
+    }
 
-    // does any (row, key) pair of this wave fall into the tile?
-    bool needed = wave_has_rows;
-    if (needed && mode != TMX_MODE_NONE) {
-      const int j0 = tile * kBlockN, j1 = j0 + kBlockN - 1;
+    // Classify the tile against this wave's rows (all wave-uniform): skip it when no (row, key) pair
+    // is attended, and skip the per-element predicate when every pair is.
+    const int j0 = tile * kBlockN, j1 = j0 + kBlockN - 1;
+    bool needed = wave_has_rows, full = false;
+    if (mode == TMX_MODE_NONE) {
+      full = j1 < n;
+    } else if (needed) {
       needed = j0 <= i_max;
-      if (needed && mode == TMX_MODE_TRIANGLE && !((n - i_max) < p.last))
-        needed = (j0 <= imin(i_max, p.si)) || (p.sl >= 0 && j1 >= i_min - p.sl);
+      full = j1 <= i_min;
+      if (mode == TMX_MODE_TRIANGLE && !wave_all_last) {
+        if (!wave_any_last) needed = needed && ((j0 <= imin(i_max, p.si)) || (p.sl >= 0 && j1 >= i_min - p.sl));
+        full = full && (j1 <= p.si || j0 >= i_max - p.sl);
+      }
     }
 
     if (needed) {
-      const char* kt = lds + (t & 1) * 2 * TILE;
+      const char* kt = lds + (t % NS) * 2 * TILE;
       const char* vt = kt + TILE;
       f32x4 s[2];
 #pragma unroll
@@ -266,31 +335,38 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
           s[kb] = TR::mfma(__builtin_bit_cast(frag, w), qf[ks], s[kb]);
         }
       }
-      // scale, bias, mask
+      // scale, bias, mask (branch free: key j is attended iff j <= key_hi and not hole_lo < j < hole_hi)
       float x[8];
-      float tmax = -__builtin_inff();
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = tile * kBlockN + 16 * kb + 4 * g + r;
-          float val = s[kb][r] * p.scale_log2;
-          bool ok = row_valid && j < n && allowed(mode, pos_i, j, n, p.si, p.sl, p.last);
-          if constexpr (HAS_BIAS) {
-            if (ok && pos_i < p.bias_rows && j < p.bias_cols)
-              val += kLog2e * load_bias(p.bias, p.bias_dtype, (int64_t)pos_i * p.bias_stride + j);
-          }
-          val = ok ? val : -__builtin_inff();
-          x[kb * 4 + r] = val;
-          tmax = fmaxf(tmax, val);
+        for (int r = 0; r < 4; ++r) x[kb * 4 + r] = s[kb][r] * p.scale_log2;
+      if constexpr (HAS_BIAS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int j = j0 + 16 * (e >> 2) + 4 * g + (e & 3);
+          if (row_valid && j < p.bias_cols && pos_i < p.bias_rows && j <= key_hi)
+            x[e] += kLog2e * load_bias(p.bias, p.bias_dtype, (int64_t)pos_i * p.bias_stride + j);
         }
+      }
+      if (!full) {
+        const int jl = j0 + 4 * g;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int j = jl + 16 * (e >> 2) + (e & 3);
+          const bool in_hole = (unsigned)(j - hole_lo - 1) < hole_width;
+          x[e] = (j <= key_hi && !in_hole) ? x[e] : -__builtin_inff();
+        }
+      }
+      float tmax = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float m_new = fmaxf(m_run, tmax);
+      // alpha rescales what was accumulated under the old maximum; nothing was when m_run is -inf
       float alpha = 1.f, m_safe = 0.f;
       if (m_new != -__builtin_inff()) {
-        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_safe = m_new;
+        if (m_run != -__builtin_inff()) alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       }
       m_run = m_new;
       float psum = 0.f;
@@ -303,10 +379,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
       }
       l_run = l_run * alpha + psum;
       const frag pf = __builtin_bit_cast(frag, pk);
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // wave-uniform: some row's maximum moved
+#pragma unroll
+        for (int db = 0; db < DB; ++db) acc[db] *= alpha;
+      }
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        acc[db] *= alpha;
-        const int so = 8 * (v_db_bits<D>(db) ^ v_x);
+        const int so = 32 * (db ^ v_x);
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4*)(vt + v_base + so));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -315,26 +394,20 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         acc[db] = TR::mfma(__builtin_bit_cast(frag, vv), pf, acc[db]);
       }
     }
-
-    if (more) write_lds((t + 1) & 1);
-    __syncthreads();
   }
 
-  // ---- epilogue ----
+  // ---- epilogue: lane (qi, g) holds columns 16*db + 4*g .. +3 of row qi for every db ----
   float l_tot = l_run + __shfl_xor(l_run, 16, 64);
   l_tot += __shfl_xor(l_tot, 32, 64);
-  if (!row_valid) return;
 
   if (slot >= 0) {
     // piece of a split q-block: unnormalised fp32 accumulator + (max, sum) for the combine pass
-    const int64_t prow = ((int64_t)slot * p.H + head) * p.block_m + (16 * rb + qi);
-    float* po = p.partial_o + prow * D;
+    if (!row_valid) return;
+    const int64_t prow = ((int64_t)slot * p.H + head) * p.block_m + my_row;
+    float* po = p.partial_o + prow * D + 4 * g;
 #pragma unroll
-    for (int c = 0; c < DB / 2; ++c) {
-      float4* dst = reinterpret_cast<float4*>(po + 32 * c + 8 * g);
-      dst[0] = make_float4(acc[2 * c][0], acc[2 * c][1], acc[2 * c][2], acc[2 * c][3]);
-      dst[1] = make_float4(acc[2 * c + 1][0], acc[2 * c + 1][1], acc[2 * c + 1][2], acc[2 * c + 1][3]);
-    }
+    for (int db = 0; db < DB; ++db)
+      *reinterpret_cast<float4*>(po + 16 * db) = make_float4(acc[db][0], acc[db][1], acc[db][2], acc[db][3]);
     if (g == 0) {
       p.partial_ml[prow * 2] = m_run;
       p.partial_ml[prow * 2 + 1] = l_tot;
@@ -343,27 +416,31 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   }
 
   const float inv = 1.0f / l_tot;  // a fully masked row gives 0 * inf = NaN, as softmax over all -inf does
-  const int64_t orow = (int64_t)(q_start + my_row) * p.out_stride_t + (int64_t)head * p.out_stride_h;
+  const int64_t orow = (int64_t)(q_tok0 + my_row) * p.out_stride_t + (int64_t)head * p.out_stride_h;
   if (p.out_dtype == TMX_F32) {
-    float* po = reinterpret_cast<float*>(p.out) + orow;
+    if (!row_valid) return;
+    float* po = reinterpret_cast<float*>(p.out) + orow + 4 * g;
 #pragma unroll
-    for (int c = 0; c < DB / 2; ++c) {
-      float4* dst = reinterpret_cast<float4*>(po + 32 * c + 8 * g);
-      dst[0] = make_float4(acc[2 * c][0] * inv, acc[2 * c][1] * inv, acc[2 * c][2] * inv, acc[2 * c][3] * inv);
-      dst[1] = make_float4(acc[2 * c + 1][0] * inv, acc[2 * c + 1][1] * inv, acc[2 * c + 1][2] * inv,
-                           acc[2 * c + 1][3] * inv);
-    }
+    for (int db = 0; db < DB; ++db)
+      *reinterpret_cast<float4*>(po + 16 * db) =
+          make_float4(acc[db][0] * inv, acc[db][1] * inv, acc[db][2] * inv, acc[db][3] * inv);
   } else {
-    uint16_t* po = reinterpret_cast<uint16_t*>(p.out) + orow;
+    // 16-bit output: lanes l and l ^ 16 exchange one 8-byte piece per pair of output blocks so that
+    // every lane stores 16 contiguous bytes (8 columns)
+    uint16_t* po = reinterpret_cast<uint16_t*>(p.out) + orow + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
 #pragma unroll
     for (int c = 0; c < DB / 2; ++c) {
-      s16x8 o;
+      s16x4 a, bq;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        o[r] = TR::cvt(acc[2 * c][r] * inv);
-        o[4 + r] = TR::cvt(acc[2 * c + 1][r] * inv);
+        a[r] = TR::cvt(acc[2 * c][r] * inv);
+        bq[r] = TR::cvt(acc[2 * c + 1][r] * inv);
       }
-      *reinterpret_cast<uint4*>(po + 32 * c + 8 * g) = __builtin_bit_cast(uint4, o);
+      uint2 au = __builtin_bit_cast(uint2, a), bu = __builtin_bit_cast(uint2, bq);
+      auto r0 = __builtin_amdgcn_permlane16_swap(au.x, bu.x, false, false);
+      auto r1 = __builtin_amdgcn_permlane16_swap(au.y, bu.y, false, false);
+      // even 16-lane rows: [own block 2c | partner's block 2c]; odd rows: [partner's block 2c+1 | own]
+      if (row_valid) *reinterpret_cast<uint4*>(po + 32 * c) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
     }
   }
 }
@@ -419,16 +496,18 @@ __global__ __launch_bounds__(256) void combine_kernel(AttnParams p) {
   }
 }
 
+constexpr int kRingSlots = 4;  // K/V tile slots in LDS; NS - 1 tiles are in flight
+
 template <typename TR, int D>
 static int launch(const AttnParams& p, bool paged, bool has_bias, dim3 grid, int64_t num_split, uint32_t flags,
                   hipStream_t s) {
   if (grid.x > 0 && !(flags & TMX_ATTN_ONLY_COMBINE)) {
     if (paged) {
-      if (has_bias) attn_kernel<TR, D, true, true><<<grid, 256, 0, s>>>(p);
-      else attn_kernel<TR, D, true, false><<<grid, 256, 0, s>>>(p);
+      if (has_bias) attn_kernel<TR, D, kRingSlots, true, true><<<grid, 256, 0, s>>>(p);
+      else attn_kernel<TR, D, kRingSlots, true, false><<<grid, 256, 0, s>>>(p);
     } else {
-      if (has_bias) attn_kernel<TR, D, false, true><<<grid, 256, 0, s>>>(p);
-      else attn_kernel<TR, D, false, false><<<grid, 256, 0, s>>>(p);
+      if (has_bias) attn_kernel<TR, D, kRingSlots, false, true><<<grid, 256, 0, s>>>(p);
+      else attn_kernel<TR, D, kRingSlots, false, false><<<grid, 256, 0, s>>>(p);
     }
     TMX_CHECK_HIP(hipGetLastError());
   }
@@ -485,7 +564,9 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
                     a->kv_stride_page % 8 == 0,
                 "tmx_attention: strides must be multiples of 8 elements");
   const bool paged = a->block_table != nullptr;
-  if (paged) TMX_CHECK_ARG(a->page_size > 0, "tmx_attention: page_size %d", a->page_size);
+  if (paged)
+    TMX_CHECK_SUPPORTED(a->page_size >= 16 && (a->page_size & (a->page_size - 1)) == 0,
+                        "tmx_attention: page_size %d not supported (powers of two >= 16 are)", a->page_size);
   else TMX_CHECK_ARG(a->cu_seqlens_k != nullptr, "tmx_attention: contiguous K/V needs cu_seqlens_k");
   const bool has_bias = a->bias != nullptr;
   if (has_bias)
@@ -520,8 +601,7 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.block_table_stride = a->block_table_stride;
   p.bias_stride = a->bias_stride;
   p.page_size = paged ? a->page_size : 1;
-  p.page_shift = -1;
-  if (paged && (a->page_size & (a->page_size - 1)) == 0) p.page_shift = __builtin_ctz(a->page_size);
+  p.page_shift = paged ? __builtin_ctz(a->page_size) : 0;
   p.H = a->num_heads;
   p.Hkv = a->num_kv_heads;
   p.G = G;

@@ -181,7 +181,13 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IndexParams p) {
       rec.y = s;
       rec.z = imax(0, imin(p.chunk, start + cnt - s));
       rec.w = pieces > 1 ? slot0 + pc : -1;
-      reinterpret_cast<int4*>(p.items)[it] = rec;
+      int4 geo;  // everything the attention kernel needs to place the q-block, so it reads nothing else
+      geo.x = b;
+      geo.y = p.cu_q[b] + r0;  // first row of the q-block in the packed q / out tensors
+      geo.z = ctx + r0;        // its position inside the sequence
+      geo.w = n;
+      reinterpret_cast<int4*>(p.items)[2 * it] = rec;
+      reinterpret_cast<int4*>(p.items)[2 * it + 1] = geo;
     }
   }
 }

@@ -155,7 +155,7 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
         return torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
 
     row_ptr, col_idx, qb_meta, part_ptr = i32(R + 1), i32(nnz), i32(2 * R), i32(R + 1)
-    items = torch.empty((max(n_items, 1), 4), dtype=torch.int32, device=dev)
+    items = torch.empty((max(n_items, 1), 8), dtype=torch.int32, device=dev)
     split_qb, totals, scratch = i32(n_split), i32(8), i32(batch + 1 + 2 * (R + 1))
     c = Index()
     c.row_ptr, c.col_idx, c.qb_meta, c.part_ptr = (row_ptr.data_ptr(), col_idx.data_ptr(), qb_meta.data_ptr(),
