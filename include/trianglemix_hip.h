@@ -140,7 +140,16 @@ typedef struct tmx_index_t {
    * TMX_MODE_CAUSAL (the reference helper's length gate,
    * trianglemix_attention.py:330-332, applied per request); 0 = no gate. */
   int32_t tri_min_len;
-  int32_t reserved;
+  /* Optional page resolution (paged K/V, block_n == 32): when tile_pages and
+   * pages_block_table are set before the build, entry e of col_idx also gets
+   * tile_pages[e] = (physical page of the tile's keys 0..15, of its keys 16..31)
+   * looked up in the request's block-table row, so that the attention kernel
+   * reads no block table.  Valid for the block table / page size it was built
+   * from; tmx_attention falls back to its own lookups for any other. */
+  int32_t pages_page_size;
+  int32_t* tile_pages;                /* (device) [nnz][2] or NULL */
+  const int32_t* pages_block_table;   /* (device) [batch, pages_block_table_stride] or NULL */
+  int64_t pages_block_table_stride;
 } tmx_index_t;
 
 /* Builds the index on the device from the device copies of the batch

@@ -107,12 +107,13 @@ def test_generator_api_and_helper(golden_selection):
 
 
 # ------------------------------------------------------------------ index
-def _build(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk=4, gate=0):
+def _build(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk=4, gate=0, block_table=None, page_size=0):
     cu_h = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
     sl_h = np.asarray(seq_lens, np.int32)
     cu = torch.from_numpy(cu_h).to(DEV)
     sld = torch.from_numpy(sl_h).to(DEV)
-    idx = ops.build_block_index(cu, sld, cu_h, sl_h, si, sl, last, bm, bn, mode, chunk_tiles=chunk, tri_min_len=gate)
+    idx = ops.build_block_index(cu, sld, cu_h, sl_h, si, sl, last, bm, bn, mode, chunk_tiles=chunk, tri_min_len=gate,
+                                block_table=block_table, page_size=page_size)
     return idx, cu, sld
 
 
@@ -186,14 +187,16 @@ def _to_dev(x, dtype):
 
 
 def _run_varlen(ops, q, k_list, v_list, q_lens, seq_lens, scale, mode, pattern, dtype=torch.bfloat16,
-                out_dtype=torch.float32, paged=False, page_size=16, bias=None, chunk=64, gate=0, q_pad=0):
+                out_dtype=torch.float32, paged=False, page_size=16, bias=None, chunk=64, gate=0, q_pad=0,
+                resolve_pages=True):
     """q: [T, H, D] float32 (already rounded); k_list/v_list: per-request [seq_len, Hkv, D]."""
     T, H, D = q.shape
     Hkv = k_list[0].shape[1]
     si, sl, last = pattern
     bm = ops.attention_block_m(H, Hkv)
-    idx, cu, sld = _build(ops, q_lens, seq_lens, si, sl, last, bm, ops.attention_block_n(), ops.MODES[mode], chunk,
-                          gate)
+    if not paged:
+        idx, cu, sld = _build(ops, q_lens, seq_lens, si, sl, last, bm, ops.attention_block_n(), ops.MODES[mode],
+                              chunk, gate)
     if q_pad:
         # rows of a wider buffer (as a slice of a fused qkv projection would be)
         buf = torch.zeros((T, H * D + q_pad), dtype=dtype, device=DEV)
@@ -218,7 +221,22 @@ def _run_varlen(ops, q, k_list, v_list, q_lens, seq_lens, scale, mode, pattern, 
                 lo, hi = pb * page_size, min((pb + 1) * page_size, s)
                 kc[blk, :hi - lo] = _to_dev(k_list[b][lo:hi], dtype)
                 vc[blk, :hi - lo] = _to_dev(v_list[b][lo:hi], dtype)
-        ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=torch.from_numpy(bt).to(DEV), bias=bias)
+        btd = torch.from_numpy(bt).to(DEV)
+        idx, cu, sld = _build(ops, q_lens, seq_lens, si, sl, last, bm, ops.attention_block_n(), ops.MODES[mode],
+                              chunk, gate, block_table=btd if resolve_pages else None, page_size=page_size)
+        if resolve_pages:
+            # the resolved pages are the block-table entries of each listed tile's two halves
+            tp = idx.tile_pages.cpu().numpy()
+            col = idx.col_idx.cpu().numpy()
+            rp = idx.row_ptr.cpu().numpy()
+            meta = idx.qb_meta.cpu().numpy()
+            for r in range(len(rp) - 1):
+                b_ = int(meta[r, 0])
+                for e in range(rp[r], rp[r + 1]):
+                    t0 = int(col[e]) * 32
+                    assert tp[e, 0] == bt[b_, t0 // page_size]
+                    assert tp[e, 1] == bt[b_, min(t0 + 16, seq_lens[b_] - 1) // page_size]
+        ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, bias=bias)
     else:
         kd = _to_dev(np.concatenate(k_list, 0), dtype)
         vd = _to_dev(np.concatenate(v_list, 0), dtype)
@@ -292,9 +310,10 @@ def test_attention_varlen_gqa_vs_oracle(dtype):
         scale = D ** -0.5
         ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], np.concatenate([[0], np.cumsum(ql)]),
                                        sl, scale, mode, *pat)
-        for paged in (False, True):
+        for paged, page_size, resolve in ((False, 0, False), (True, 16, True), (True, 64, ci % 2 == 0)):
             got = _run_varlen(_ops(), q, ks, vs, ql, sl, scale, mode, pat, dtype=dtype, paged=paged,
-                              chunk=(4 if ci % 2 else 64), q_pad=(64 if ci % 3 == 0 else 0))
+                              page_size=page_size, chunk=(4 if ci % 2 else 64), q_pad=(64 if ci % 3 == 0 else 0),
+                              resolve_pages=resolve)
             assert not np.isnan(got).any(), (ci, paged)
             err = np.abs(got - ref).max()
             assert err <= ATOL_F32_OUT, (ci, paged, err)

@@ -13,7 +13,7 @@ ap.add_argument("--heads", type=int, default=32)
 ap.add_argument("--kv", type=int, default=8)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--chunks", type=str, default="64")
-ap.add_argument("--paged", type=int, default=1)
+ap.add_argument("--paged", type=int, default=1, help="0 contiguous, 1 paged with resolved pages, 2 paged with in-kernel lookups")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 n, H, Hkv, D = args.n, args.heads, args.kv, 128
@@ -51,7 +51,8 @@ for name, (si, sl_, last), mode in (("triangle(4,32,64)", (4, 32, 64), "triangle
             iters = 3
         else:
             iters = args.iters
-        idx = ops.build_block_index(cu, sl, cu_h, sl_h, si, sl_, last, bm, bn, ops.MODES[mode], chunk_tiles=chunk)
+        idx = ops.build_block_index(cu, sl, cu_h, sl_h, si, sl_, last, bm, bn, ops.MODES[mode], chunk_tiles=chunk,
+                                    block_table=bt if args.paged == 1 else None, page_size=PAGE)
         work = ops.alloc_workspace(idx, H, D, dev)
         def run(flags=TMX_ATTN_SKIP_COMBINE):
             if args.paged:

@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrianglemix_hip.so")
+LIB_PATH = os.environ.get("TMX_LIB_PATH") or os.path.join(_HERE, "libtrianglemix_hip.so")
 
 TMX_OK, TMX_ERR_INVALID_ARG, TMX_ERR_UNSUPPORTED, TMX_ERR_HIP, TMX_ERR_CAPACITY = range(5)
 TMX_F32, TMX_BF16, TMX_F16, TMX_FP8_E4M3 = range(4)
@@ -42,7 +42,8 @@ class Index(Structure):
                 ("cap_qblocks", c_int64), ("cap_nnz", c_int64), ("cap_items", c_int64), ("cap_split", c_int64),
                 ("block_m", c_int32), ("block_n", c_int32), ("mode", c_int32), ("chunk_tiles", c_int32),
                 ("si", c_int32), ("sl", c_int32), ("last", c_int32), ("batch", c_int32),
-                ("tri_min_len", c_int32), ("reserved", c_int32)]
+                ("tri_min_len", c_int32), ("pages_page_size", c_int32),
+                ("tile_pages", c_void_p), ("pages_block_table", c_void_p), ("pages_block_table_stride", c_int64)]
 
 
 class AttentionArgs(Structure):

@@ -17,6 +17,7 @@ namespace tmx {
 
 constexpr int kBlockN = 32;     // keys per tile of the attention kernel
 constexpr int kWavesPerWG = 4;  // waves of one attention workgroup
+constexpr int kRowBlocksPerWave = 2;  // 16-row blocks of one query head each wave computes
 constexpr float kLog2e = 1.4426950408889634f;
 
 TMX_HD int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -34,7 +35,7 @@ TMX_HD int gcd_int(int a, int b) {
 
 // Heads of one K/V group handled by one workgroup, and 16-row blocks per workgroup.
 TMX_HD int heads_per_wg(int group) { return gcd_int(group, kWavesPerWG); }
-TMX_HD int block_m_for_group(int group) { return 16 * (kWavesPerWG / heads_per_wg(group)); }
+TMX_HD int block_m_for_group(int group) { return 16 * kRowBlocksPerWave * (kWavesPerWG / heads_per_wg(group)); }
 
 // The triangle pattern applies to requests longer than the gate only.
 TMX_HD int effective_mode(int mode, int n, int tri_min_len) {

@@ -61,6 +61,10 @@ struct IndexParams {
   int32_t* items;
   int32_t* split_qb;
   int32_t* totals;
+  int32_t* tile_pages;        // [nnz][2] or NULL
+  const int32_t* block_table;  // for tile_pages
+  long long block_table_stride;
+  int page_shift;
   int32_t* seq_qb_ptr;  // scratch [batch + 1]
   int32_t* piece_ptr;   // scratch [R + 1]
   int batch, block_m, block_n, mode, chunk, si, sl, last, tri_min_len;
@@ -166,7 +170,18 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IndexParams p) {
   const int cnt = tr.count();
   const int start = p.row_ptr[qb];
   for (int e = lane; e < cnt; e += 64)
-    if (start + e < p.cap_nnz) p.col_idx[start + e] = tr.tile_at(e);
+    if (start + e < p.cap_nnz) {
+      const int tile = tr.tile_at(e);
+      p.col_idx[start + e] = tile;
+      if (p.tile_pages != nullptr) {
+        // physical pages of the tile's two 16-key halves (keys past the end share the last page)
+        const int32_t* bt = p.block_table + (long long)b * p.block_table_stride;
+        int2 pg;
+        pg.x = bt[(tile * p.block_n) >> p.page_shift];
+        pg.y = bt[imin(tile * p.block_n + 16, n - 1) >> p.page_shift];
+        reinterpret_cast<int2*>(p.tile_pages)[start + e] = pg;
+      }
+    }
   // work items: q-blocks descending, pieces ascending
   const int pieces = imax(1, ceil_div(cnt, p.chunk));
   const int total_pieces = p.piece_ptr[num_qblocks];
@@ -236,6 +251,20 @@ extern "C" int tmx_build_block_index(tmx_index_t* idx, const int32_t* cu_q_dev, 
   p.items = idx->items;
   p.split_qb = idx->split_qb;
   p.totals = idx->totals;
+  p.tile_pages = nullptr;
+  p.block_table = nullptr;
+  p.block_table_stride = 0;
+  p.page_shift = 0;
+  if (idx->tile_pages != nullptr && idx->pages_block_table != nullptr) {
+    TMX_CHECK_SUPPORTED(idx->block_n == 32 && idx->pages_page_size >= 16 &&
+                            (idx->pages_page_size & (idx->pages_page_size - 1)) == 0,
+                        "tmx_build_block_index: page resolution needs block_n 32 and a power-of-two page size >= 16");
+    TMX_CHECK_ARG((reinterpret_cast<uintptr_t>(idx->tile_pages) & 7) == 0, "tmx_build_block_index: tile_pages must be 8-byte aligned");
+    p.tile_pages = idx->tile_pages;
+    p.block_table = idx->pages_block_table;
+    p.block_table_stride = idx->pages_block_table_stride;
+    p.page_shift = __builtin_ctz(idx->pages_page_size);
+  }
   p.seq_qb_ptr = idx->scratch;
   p.piece_ptr = idx->scratch + idx->batch + 1;
   p.batch = idx->batch;

@@ -122,6 +122,8 @@ class BlockIndex:
     last: int
     chunk_tiles: int
     tri_min_len: int = 0
+    tile_pages: Optional[torch.Tensor] = None
+    block_table: Optional[torch.Tensor] = None  # kept alive: the C struct points at it
 
     @property
     def num_qblocks(self) -> int:
@@ -134,9 +136,12 @@ class BlockIndex:
 
 def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seqlens_q_cpu, seq_lens_cpu,
                       si: int, sl: int, last: int, block_m: int, block_n: int, mode: int,
-                      chunk_tiles: int = DEFAULT_CHUNK_TILES, tri_min_len: int = 0) -> BlockIndex:
+                      chunk_tiles: int = DEFAULT_CHUNK_TILES, tri_min_len: int = 0,
+                      block_table: Optional[torch.Tensor] = None, page_size: int = 0) -> BlockIndex:
     """Build the packed block-sparse index on the device (two launches, no
-    host synchronisation; buffer sizes come from the host copies)."""
+    host synchronisation; buffer sizes come from the host copies).  With a
+    ``block_table`` (int32 ``[B, max_blocks]``) and ``page_size`` the physical
+    pages of every listed tile are resolved as well (paged K/V, ``block_n`` 32)."""
     _require_gpu(cu_seqlens_q, "cu_seqlens_q")
     _require_gpu(seq_lens, "seq_lens")
     if cu_seqlens_q.dtype != torch.int32 or seq_lens.dtype != torch.int32:
@@ -165,14 +170,25 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
     c.cap_qblocks, c.cap_nnz, c.cap_items, c.cap_split = R, nnz, n_items, n_split
     c.block_m, c.block_n, c.mode, c.chunk_tiles = block_m, block_n, mode, chunk_tiles
     c.si, c.sl, c.last, c.batch = si, sl, last, batch
-    c.tri_min_len, c.reserved = tri_min_len, 0
+    c.tri_min_len = tri_min_len
+    tile_pages = None
+    if block_table is not None:
+        _require_gpu(block_table, "block_table")
+        if block_table.dtype != torch.int32 or block_table.dim() != 2 or block_table.stride(1) != 1:
+            raise RuntimeError("block_table must be int32 [B, max_blocks] with contiguous rows")
+        tile_pages = torch.empty((max(nnz, 1), 2), dtype=torch.int32, device=dev)
+        c.tile_pages, c.pages_block_table = tile_pages.data_ptr(), block_table.data_ptr()
+        c.pages_block_table_stride, c.pages_page_size = block_table.stride(0), int(page_size)
+    else:
+        c.tile_pages, c.pages_block_table, c.pages_block_table_stride, c.pages_page_size = None, None, 0, 0
     with torch.cuda.device(dev):
         check(_lib.load().tmx_build_block_index(ctypes.byref(c), _ptr(cu_seqlens_q), _ptr(seq_lens),
                                                 cu_h.ctypes.data_as(ctypes.c_void_p),
                                                 sl_h.ctypes.data_as(ctypes.c_void_p), _stream(dev)))
     return BlockIndex(row_ptr[:R + 1], col_idx[:nnz], qb_meta[:2 * R].view(R, 2) if R else qb_meta[:0].view(0, 2),
                       part_ptr[:R + 1], items[:n_items], split_qb[:n_split], totals, scratch, sz, c, batch,
-                      block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len)
+                      block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
+                      None if tile_pages is None else tile_pages[:nnz], block_table)
 
 
 # --------------------------------------------------------------------------- attention
@@ -242,11 +258,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     sz = index.sizes
     a.num_items, a.num_partials, a.num_split_qblocks = sz.num_items, sz.num_partials, sz.num_split_qblocks
     part_o = part_ml = None
+    if workspace is not None:
+        part_o, part_ml = workspace
+    elif sz.num_partials > 0:
+        part_o, part_ml = alloc_workspace(index, H, D, q.device)
     if sz.num_partials > 0:
-        if workspace is not None:
-            part_o, part_ml = workspace
-        else:
-            part_o, part_ml = alloc_workspace(index, H, D, q.device)
         need = int(sz.num_partials) * H * index.block_m
         if part_o.numel() < need * D or part_ml.numel() < need * 2 or part_o.dtype != torch.float32:
             raise RuntimeError("attention workspace too small for this index")
