@@ -149,6 +149,7 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 // Issued from inline asm on purpose: the compiler would otherwise wait for ALL
 // transfers in flight (vmcnt(0)) before every LDS read; here the waits are
 // counted by hand and followed by a workgroup barrier.
+// Form 1: per-lane 64-bit address.
 __device__ __forceinline__ void glds16(const void* src, unsigned lds_addr) {
   unsigned keep;
   asm volatile(
@@ -159,6 +160,19 @@ __device__ __forceinline__ void glds16(const void* src, unsigned lds_addr) {
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(src), "s"(lds_addr)
+      : "memory");
+}
+// Form 2: wave-uniform 64-bit base + per-lane 32-bit byte offset (no vector address arithmetic).
+__device__ __forceinline__ void glds16_s(const void* sbase, int voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr)
       : "memory");
 }
 
@@ -177,23 +191,19 @@ __device__ __forceinline__ void glds16(const void* src, unsigned lds_addr) {
 #define TMX_SEG(idx, t0, t1) do { } while (0)
 #endif
 
-// What one workgroup needs to know about a unit of work (all wave-uniform):
-// a q-block piece from the index; the K/V head is fixed per workgroup.
-struct Unit {
-  int valid;
-  int col_start, ntiles, slot, b, q_tok0, pos0, n;
-};
+// Running maximum before any key was seen: finite, so that exp2(m_old - m_new) and exp2(-inf - m)
+// need no special cases (scores are finite; a fully masked row still ends with sum 0 -> NaN).
+constexpr float kMinusBig = -1.0e30f;
 
-// Persistent, software-pipelined kernel.  Every workgroup walks units
-// blockIdx.x, blockIdx.x + gridDim.x, ... and streams their inputs through ONE
-// ring of NS LDS entries of equal size: per unit first RB "Q entries" (the
-// 16 * RB rows of every wave), then one entry per key tile ([K | V], 32 keys).
+// Persistent, software-pipelined kernel.  Every workgroup walks work items
+// item0, item0 + step, ... for ONE K/V head chunk and streams their inputs
+// through a ring of NS LDS entries of equal size: per item first RB "Q entries"
+// (16 rows per wave each), then one entry per key tile ([K | V], 32 keys).
 // Entries are fetched by LDS-DMA NS - 1 entries ahead of their use, across
-// unit boundaries, so the loads of the next unit are in flight while the
-// current one is computed and stored.  A unit is (work item, K/V head chunk);
-// the grid is a multiple of the chunks per item, so a workgroup keeps its chunk.
+// item boundaries, so the loads of the next item are in flight while the
+// current one is computed and stored.
 template <typename TR, int D, int NS, int RB, bool PAGED, bool HAS_BIAS>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   constexpr int KS = D / 32;            // k-steps of S^T = K Q^T
   constexpr int DB = D / 16;            // 16-column output blocks
   constexpr int ROWB = D * 2;           // bytes per Q/K/V row in LDS
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
   constexpr int RPP = 1024 / ROWB;      // rows per 1-KiB LDS-DMA piece (one wave instruction)
   constexpr int DPT = ENTRY / 1024 / 4; // LDS-DMA instructions per wave and entry
   constexpr int U = DPT / 2;            // ... per tensor of a K/V entry
+  static_assert((NS & (NS - 1)) == 0, "ring size must be a power of two");
   using frag = typename TR::frag;
 
   __shared__ __attribute__((aligned(16))) char lds[NS * ENTRY];
@@ -216,122 +227,159 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 
   const int hg = wave % p.Gw;           // this wave's head inside the workgroup's head group
   const int rbw = (wave / p.Gw) * RB;   // its first 16-row block inside the q-block
-  const int W = gridDim.x;
-  // fixed for the workgroup: K/V head and first query head of its chunk
+  // fixed for the workgroup: K/V head and query head (the grid is a multiple of Y, or has <= Y workgroups)
   const int kvc = blockIdx.x % p.Y;
   const int chunks = p.G / p.Gw;
   const int kvh = kvc / chunks;
   const int head = kvh * p.G + (kvc - kvh * chunks) * p.Gw + hg;
-  const int item0 = blockIdx.x / p.Y, item_step = W / p.Y;  // W is a multiple of Y, or every workgroup has one unit
+  const int item0 = blockIdx.x / p.Y;
+  const int item_step = (int)gridDim.x / p.Y;  // 0: every workgroup has a single item
 
-  auto load_unit = [&](int k) -> Unit {
-    Unit u;
-    const long long item = item0 + (long long)k * item_step;
-    u.valid = (item < p.num_items) && (k == 0 || item_step > 0);
-    u.col_start = u.ntiles = u.slot = u.b = u.q_tok0 = u.pos0 = 0;
-    u.n = 1;
-    if (u.valid) {
-      const i32x4 it0 = sload(reinterpret_cast<const i32x4*>(p.items) + 2 * item);
-      const i32x4 it1 = sload(reinterpret_cast<const i32x4*>(p.items) + 2 * item + 1);
-      u.col_start = it0.y;
-      u.ntiles = it0.z;
-      u.slot = it0.w;
-      u.b = it1.x;
-      u.q_tok0 = it1.y;
-      u.pos0 = it1.z;
-      u.n = it1.w;
-    }
-    return u;
-  };
+  const char* const qbytes = reinterpret_cast<const char*>(p.q) + 2ll * head * p.q_stride_h;
+  const char* const kbytes = reinterpret_cast<const char*>(p.k) + 2ll * kvh * p.kv_stride_h;
+  const char* const vbytes = reinterpret_cast<const char*>(p.v) + 2ll * kvh * p.kv_stride_h;
+  const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = 2 * p.kv_stride_t;
 
-  // ------------------------------------------------------------------ issue side
-  Unit iu = load_unit(0);
-  Unit iu_next = load_unit(1);
-  int ik = 0;   // ordinal of iu among this workgroup's units
-  int ie = 0;   // entries of iu already issued
-  int gi = 0;   // entries issued so far (ring position)
-  // descriptor of the next K/V entry to issue, fetched one step ahead: key tile and the page offsets
-  // (elements) of its two 16-key halves
-  int d_tile = 0;
-  long long d_off0 = 0, d_off1 = 0;
-  long long i_krow0 = 0;  // contiguous K/V: first row of iu's request
-
+  // ---- per-lane constants of the LDS-DMA issue: byte offsets relative to a wave-uniform base ----
   const int piece_row = lane / CPR;  // row of this lane inside a 1-KiB piece
   const int piece_cc = lane % CPR;   // its 16-byte chunk
-  const uint16_t* qbase = reinterpret_cast<const uint16_t*>(p.q) + (long long)head * p.q_stride_h;
-  const uint16_t* kbase = reinterpret_cast<const uint16_t*>(p.k) + (long long)kvh * p.kv_stride_h;
-  const uint16_t* vbase = reinterpret_cast<const uint16_t*>(p.v) + (long long)kvh * p.kv_stride_h;
+  int q_voff[DPT];                   // Q entry: rows x * RPP + piece_row of this wave's 16-row block
+#pragma unroll
+  for (int x = 0; x < DPT; ++x) {
+    const int r16 = x * RPP + piece_row;
+    q_voff[x] = r16 * q_row_bytes + 16 * (piece_cc ^ k_chunk_swizzle<D>(r16));
+  }
+  int k_voff[U], v_voff[U];          // K/V entry: rows (wave * U + x) * RPP + piece_row of the 32-key tile
+#pragma unroll
+  for (int x = 0; x < U; ++x) {
+    const int row = (wave * U + x) * RPP + piece_row;
+    k_voff[x] = row * kv_row_bytes + 16 * (piece_cc ^ k_chunk_swizzle<D>(row));
+    v_voff[x] = row * kv_row_bytes + 16 * (piece_cc ^ v_chunk_swizzle<D>(row));
+  }
 
-  // start fetching what the NEXT issue of a K/V entry needs (no wait here)
+  // ------------------------------------------------------------------ issue side (all scalar)
+  // current issue item and the one after it (fetched ahead)
+  i32x4 ia0, ia1, ib0, ib1;
+  int i_valid, ib_valid;
+  auto fetch_item = [&](int k, i32x4& a0, i32x4& a1) -> int {
+    const long long item = item0 + (long long)k * item_step;
+    const int ok = (item < p.num_items) && (k == 0 || item_step > 0);
+    a0 = a1 = i32x4{0, 0, 0, 1};
+    if (ok) {
+      a0 = sload(reinterpret_cast<const i32x4*>(p.items) + 2 * item);
+      a1 = sload(reinterpret_cast<const i32x4*>(p.items) + 2 * item + 1);
+    }
+    return ok;
+  };
+  i_valid = fetch_item(0, ia0, ia1);
+  ib_valid = fetch_item(1, ib0, ib1);
+  int ik = 0;   // ordinal of the issue item among this workgroup's items
+  int ie = 0;   // its entries already issued
+  int gi = 0;   // entries issued so far (ring position)
+  // descriptor of the next K/V entry to issue, fetched one step ahead
+  int d_tile = 0;
+  long long d_off0 = 0, d_off1 = 0;  // byte offsets of the pages holding the tile's keys 0..15 / 16..31
+  long long i_krow0 = 0;             // contiguous K/V: first row of the issue item's request
+
   auto prefetch_desc = [&]() {
-    if (!iu.valid || ie < RB || ie >= RB + iu.ntiles) return;
-    const int pos = iu.col_start + (ie - RB);
+    // item fields: a0 = (qb, col_start, ntiles, slot), a1 = (b, q_tok0, pos0, n)
+    if (!i_valid || ie < RB || ie >= RB + ia0.z) return;
+    const int pos = ia0.y + (ie - RB);
     d_tile = sload(p.col_idx + pos);
     if constexpr (PAGED) {
       if (p.tile_pages != nullptr) {
-        d_off0 = (long long)sload(p.tile_pages + 2 * pos) * p.kv_stride_page;
-        d_off1 = (long long)sload(p.tile_pages + 2 * pos + 1) * p.kv_stride_page;
+        d_off0 = 2ll * sload(p.tile_pages + 2 * pos) * p.kv_stride_page;
+        d_off1 = 2ll * sload(p.tile_pages + 2 * pos + 1) * p.kv_stride_page;
       } else {
-        const int32_t* bt = p.block_table + (long long)iu.b * p.block_table_stride;
+        const int32_t* bt = p.block_table + (long long)ia1.x * p.block_table_stride;
         const int pg_first = (d_tile * kBlockN) >> p.page_shift;
-        d_off0 = (long long)sload(bt + pg_first) * p.kv_stride_page;
-        d_off1 = (long long)sload(bt + imin(pg_first + 1, (iu.n - 1) >> p.page_shift)) * p.kv_stride_page;
+        d_off0 = 2ll * sload(bt + pg_first) * p.kv_stride_page;
+        d_off1 = 2ll * sload(bt + (imin(d_tile * kBlockN + 16, ia1.w - 1) >> p.page_shift)) * p.kv_stride_page;
       }
     }
   };
 
   auto issue_one = [&]() {
-    const unsigned dst = lds_base + ((unsigned)gi % NS) * ENTRY;
+    const unsigned dst = lds_base + ((unsigned)gi & (NS - 1)) * ENTRY;
+    const int n = ia1.w;
     if (ie < RB) {
-      // Q entry: this wave's 16 rows of row block rbw + ie, head `head`
-      const int rows_valid = imin(p.block_m, iu.n - iu.pos0);
+      // Q entry: this wave's 16 rows of row block rbw + ie
+      const int rows_valid = imin(p.block_m, n - ia1.z);
+      const int r0 = 16 * (rbw + ie);
+      const unsigned qdst = dst + wave * (ENTRY / 4);
+      if (r0 + 16 <= rows_valid) {
+        const char* sb = qbytes + (long long)(ia1.y + r0) * q_row_bytes;
 #pragma unroll
-      for (int x = 0; x < DPT; ++x) {
-        const int r16 = x * RPP + piece_row;  // row inside the 16-row block
-        // rows past the end of the request are never stored; read a valid row instead
-        const int r = imin(16 * (rbw + ie) + r16, rows_valid - 1);
-        glds16(qbase + (long long)(iu.q_tok0 + r) * p.q_stride_t + 8 * (piece_cc ^ k_chunk_swizzle<D>(r16)),
-               dst + wave * (ENTRY / 4) + x * 1024);
+        for (int x = 0; x < DPT; ++x) glds16_s(sb, q_voff[x], qdst + x * 1024);
+      } else {
+        // ragged last block: rows past the end of the request are never stored; read a valid row instead
+#pragma unroll
+        for (int x = 0; x < DPT; ++x) {
+          const int r16 = x * RPP + piece_row;
+          const int r = imax(0, imin(r0 + r16, rows_valid - 1));
+          glds16(qbytes + (long long)(ia1.y + r) * q_row_bytes + 16 * (piece_cc ^ k_chunk_swizzle<D>(r16)),
+                 qdst + x * 1024);
+        }
       }
     } else {
-      const int last_key = iu.n - 1;
-      const int pg_first = PAGED ? ((d_tile * kBlockN) >> p.page_shift) : 0;
-#pragma unroll
-      for (int x = 0; x < U; ++x) {
-        const int piece = wave * U + x;
-        const int row = piece * RPP + piece_row;
-        // keys past the end of the sequence are masked later; clamp their source to a valid row
-        const int j = imin(d_tile * kBlockN + row, last_key);
-        long long off;
+      const int j0 = d_tile * kBlockN;
+      if (j0 + kBlockN <= n) {
+        // whole tile inside the sequence: one wave-uniform base per 16-key half
+        long long b0, b1;
         if constexpr (PAGED) {
-          off = ((j >> p.page_shift) == pg_first ? d_off0 : d_off1) + (j & (p.page_size - 1)) * p.kv_stride_t;
+          const long long in_page = (long long)(j0 & (p.page_size - 1)) * kv_row_bytes;
+          b0 = d_off0 + in_page;
+          b1 = (p.page_size > 16) ? b0 : d_off1 - 16ll * kv_row_bytes;
         } else {
-          off = (i_krow0 + j) * p.kv_stride_t;
+          b0 = b1 = (i_krow0 + j0) * kv_row_bytes;
         }
-        glds16(kbase + off + 8 * (piece_cc ^ k_chunk_swizzle<D>(row)), dst + piece * 1024);
-        glds16(vbase + off + 8 * (piece_cc ^ v_chunk_swizzle<D>(row)), dst + HALF + piece * 1024);
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+          const int piece = wave * U + x;
+          const long long bb = (piece * RPP >= 16) ? b1 : b0;
+          glds16_s(kbytes + bb, k_voff[x], dst + piece * 1024);
+          glds16_s(vbytes + bb, v_voff[x], dst + HALF + piece * 1024);
+        }
+      } else {
+        // last, partial tile: keys past the end are masked later; clamp their source to the last key
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+          const int piece = wave * U + x;
+          const int row = piece * RPP + piece_row;
+          const int j = imin(j0 + row, n - 1);
+          long long off;
+          if constexpr (PAGED) {
+            off = (((j - j0) >= 16 && p.page_size == 16) ? d_off1 : d_off0) + (long long)(j & (p.page_size - 1)) * kv_row_bytes;
+          } else {
+            off = (i_krow0 + j) * kv_row_bytes;
+          }
+          glds16(kbytes + off + 16 * (piece_cc ^ k_chunk_swizzle<D>(row)), dst + piece * 1024);
+          glds16(vbytes + off + 16 * (piece_cc ^ v_chunk_swizzle<D>(row)), dst + HALF + piece * 1024);
+        }
       }
     }
     ++ie;
     ++gi;
-    if (ie == RB + iu.ntiles) {
-      iu = iu_next;
+    if (ie == RB + ia0.z) {
+      ia0 = ib0;
+      ia1 = ib1;
+      i_valid = ib_valid;
       ++ik;
-      iu_next = load_unit(ik + 1);
+      ib_valid = fetch_item(ik + 1, ib0, ib1);
       ie = 0;
       if constexpr (!PAGED) {
-        if (iu.valid) i_krow0 = sload(p.cu_k + iu.b);
+        if (i_valid) i_krow0 = sload(p.cu_k + ia1.x);
       }
     }
     prefetch_desc();
   };
 
   if constexpr (!PAGED) {
-    if (iu.valid) i_krow0 = sload(p.cu_k + iu.b);
+    if (i_valid) i_krow0 = sload(p.cu_k + ia1.x);
   }
 #pragma unroll 1
   for (int x = 0; x < NS - 1; ++x)
-    if (iu.valid) issue_one();
+    if (i_valid) issue_one();
 
   // ------------------------------------------------------------------ compute side
   // per-lane LDS read offsets inside an entry
@@ -342,11 +390,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
   // second half of the tile), columns 16 * db + 4 * pp .. +3
   const int v_row = 4 * g + ((lane & 15) >> 2);
   const int v_x = v_chunk_swizzle<D>(v_row) >> 1;  // XOR on the 32-byte group index == the output block db
-  const int v_base = HALF + v_row * ROWB + 8 * (lane & 3);
+  int v_off[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db) v_off[db] = HALF + v_row * ROWB + 8 * (lane & 3) + 32 * (db ^ v_x);
   const int koff_lane = 4 * g;  // this lane's first key inside a 16-key half tile
 
-  Unit cu = load_unit(0);
-  Unit cu_next = load_unit(1);
+  i32x4 ca0, ca1, cb0, cb1;
+  int c_valid = fetch_item(0, ca0, ca1);
+  int cb_valid = fetch_item(1, cb0, cb1);
   int ck = 0;
   int gs = 0;          // entries consumed so far
   int store_mark = 0;  // entries with ring position < store_mark were issued before the last stores
@@ -359,28 +410,55 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
   const unsigned long long t_begin = ts4;
 #endif
 
-  while (cu.valid) {
-    const int rows_valid = imin(p.block_m, cu.n - cu.pos0);
-    const int mode = effective_mode(p.mode, cu.n, p.tri_min_len);
-    const int n = cu.n;
+  // Wait for ring entry gs, make it visible to the workgroup, refill the slot freed one step ago.
+  auto step_sync = [&]() {
+    TMX_STAMP(ts0);
+    const int younger = DPT * (gi - gs - 1) + (gs < store_mark ? store_ops : 0);
+    wait_vmcnt_dyn<0, 15>(younger);
+    TMX_STAMP(ts1);
+    __builtin_amdgcn_s_barrier();
+    TMX_STAMP(ts2);
+    if (i_valid) issue_one();
+    TMX_STAMP(ts3);
+    TMX_SEG(0, ts0, ts1);
+    TMX_SEG(1, ts1, ts2);
+    TMX_SEG(2, ts2, ts3);
+  };
 
-    // ---- per row block: wave-uniform row ranges and the per-lane form of the predicate ----
-    // key j is attended by this lane's row iff j <= key_hi and not (hole_lo < j < hole_lo + 1 + hole_width)
-    int i_min[RB], i_max[RB], key_hi[RB];
-    unsigned hole_width[RB];
-    bool has_rows[RB], any_last[RB], all_last[RB], row_valid[RB];
-    const int hole_lo = p.si < -1 ? -1 : p.si;
+  while (c_valid) {
+    const int col_start = ca0.y, ntiles = ca0.z, slot = ca0.w;
+    const int q_tok0 = ca1.y, pos0 = ca1.z, n = ca1.w;
+    const int rows_valid = imin(p.block_m, n - pos0);
+    const int mode = effective_mode(p.mode, n, p.tri_min_len);
+
+    // ---- Q fragments of this wave's RB row blocks (B operand of S^T) ----
+    frag qf[RB][KS];
 #pragma unroll
     for (int e = 0; e < RB; ++e) {
-      const int wrow0 = 16 * (rbw + e);
-      const int wrow1 = imin(wrow0 + 16, rows_valid);
-      has_rows[e] = wrow0 < rows_valid;
-      i_min[e] = cu.pos0 + wrow0;
-      i_max[e] = cu.pos0 + wrow1 - 1;
-      any_last[e] = (n - i_max[e]) < p.last;
-      all_last[e] = (n - i_min[e]) < p.last;
-      row_valid[e] = wrow0 + qi < rows_valid;
-      const int pos_i = cu.pos0 + wrow0 + qi;
+      step_sync();
+      const char* qs = lds + ((unsigned)gs & (NS - 1)) * ENTRY + wave * (ENTRY / 4);
+      ++gs;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        qf[e][ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(qs + k_off[ks]));
+    }
+
+    // ---- wave-uniform row range of the wave's 16 * RB rows, per-lane form of the predicate ----
+    // key j is attended by this lane's row iff j <= key_hi and not (hole_lo < j < hole_lo + 1 + hole_width)
+    const int w_row0 = 16 * rbw;
+    const int w_row1 = imin(w_row0 + 16 * RB, rows_valid);
+    const bool w_has_rows = w_row0 < rows_valid;
+    const int w_imin = pos0 + w_row0, w_imax = pos0 + w_row1 - 1;
+    const bool w_all_last = (n - w_imin) < p.last;
+    const int hole_lo = p.si < -1 ? -1 : p.si;
+    int key_hi[RB];
+    unsigned hole_width[RB];
+    bool row_valid[RB];
+#pragma unroll
+    for (int e = 0; e < RB; ++e) {
+      const int my_row = w_row0 + 16 * e + qi;
+      row_valid[e] = my_row < rows_valid;
+      const int pos_i = pos0 + my_row;
       key_hi[e] = -1;
       hole_width[e] = 0;
       if (row_valid[e]) {
@@ -393,171 +471,105 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
       }
     }
 
-    frag qf[RB][KS];
     f32x4 acc[RB][DB];
     float m_run[RB], l_run[RB];
 #pragma unroll
     for (int e = 0; e < RB; ++e) {
-      m_run[e] = -__builtin_inff();
+      m_run[e] = kMinusBig;
       l_run[e] = 0.f;
 #pragma unroll
       for (int db = 0; db < DB; ++db) acc[e][db] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    const int n_entries = RB + cu.ntiles;
-    int tile = cu.ntiles > 0 ? sload(p.col_idx + cu.col_start) : 0;
+    int tile = ntiles > 0 ? sload(p.col_idx + col_start) : 0;
 #pragma unroll 1
-    for (int ent = 0; ent < n_entries; ++ent) {
-      // ---- wait for ring entry gs, make it visible to the workgroup, refill the slot freed last step
-      TMX_STAMP(ts0);
-      wait_vmcnt_dyn<0, 15>(DPT * (gi - gs - 1) + (gs < store_mark ? store_ops : 0));
-      TMX_STAMP(ts1);
-      __builtin_amdgcn_s_barrier();
-      TMX_STAMP(ts2);
-      if (iu.valid) issue_one();
-      TMX_STAMP(ts3);
-      TMX_SEG(0, ts0, ts1);
-      TMX_SEG(1, ts1, ts2);
-      TMX_SEG(2, ts2, ts3);
-      const char* es = lds + ((unsigned)gs % NS) * ENTRY;
+    for (int t = 0; t < ntiles; ++t) {
+      step_sync();
+      const unsigned eoff = ((unsigned)gs & (NS - 1)) * ENTRY;
+      const char* es = lds + eoff;
       ++gs;
+      const int j0 = tile * kBlockN, j1 = j0 + kBlockN - 1;
+      if (t + 1 < ntiles) tile = sload(p.col_idx + col_start + t + 1);  // for the next iteration
 
-      if (ent < RB) {
-        // Q fragments of row block `ent` (B operand of S^T)
-        const char* qs = es + wave * (ENTRY / 4);
-#pragma unroll
-        for (int e = 0; e < RB; ++e)
-          if (e == ent) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-              qf[e][ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(qs + k_off[ks]));
-          }
-        continue;
+      // `full`: every (row, key) pair of the wave's rows and this tile is attended (wave-uniform),
+      // so the per-element predicate is skipped.  Everything else goes through the predicate.
+      bool full;
+      if (mode == TMX_MODE_NONE) {
+        full = j1 < n;
+      } else {
+        full = j1 <= w_imin;
+        if (mode == TMX_MODE_TRIANGLE && !w_all_last) full = full && (j1 <= p.si || j0 >= w_imax - p.sl);
       }
-      const int t = ent - RB;
-      const int j0 = tile * kBlockN;
-      if (t + 1 < cu.ntiles) tile = sload(p.col_idx + cu.col_start + t + 1);  // next iteration's tile
-
-      // Classify each 16-key half of the tile against each row block (wave-uniform): `need`: some
-      // (row, key) pair is attended; `full`: every pair is, so the per-element predicate is skipped.
-      bool need[RB][2], full[RB], kb_used[2] = {false, false};
-#pragma unroll
-      for (int e = 0; e < RB; ++e) {
-        full[e] = false;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const int h0 = j0 + 16 * kb, h1 = h0 + 15;
-          bool nd = has_rows[e] && h0 < n;
-          if (mode != TMX_MODE_NONE && nd) {
-            nd = h0 <= i_max[e];
-            if (mode == TMX_MODE_TRIANGLE && !any_last[e])
-              nd = nd && ((h0 <= imin(i_max[e], p.si)) || (p.sl >= 0 && h1 >= i_min[e] - p.sl));
-          }
-          need[e][kb] = nd;
-          kb_used[kb] = kb_used[kb] || nd;
-        }
-        const int j1 = j0 + kBlockN - 1;
-        if (mode == TMX_MODE_NONE) {
-          full[e] = j1 < n;
-        } else {
-          full[e] = j1 <= i_min[e];
-          if (mode == TMX_MODE_TRIANGLE && !all_last[e]) full[e] = full[e] && (j1 <= p.si || j0 >= i_max[e] - p.sl);
-        }
-      }
-      if (!kb_used[0] && !kb_used[1]) continue;
+      if (!w_has_rows) continue;
       TMX_STAMP(ts0);
 
-      // S^T = K Q^T: K fragments are read once for all row blocks; unused halves are skipped
+      // S^T = K Q^T: K fragments are read once for all row blocks
       f32x4 s[RB][2];
 #pragma unroll
       for (int e = 0; e < RB; ++e) s[e][0] = s[e][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        if (!kb_used[kb]) continue;
-        frag kf[KS];
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          kf[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(es + kb * 16 * ROWB + k_off[ks]));
+        for (int ks = 0; ks < KS; ++ks) {
+          const frag kf = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(es + kb * 16 * ROWB + k_off[ks]));
 #pragma unroll
-        for (int e = 0; e < RB; ++e) {
-          if (!need[e][kb]) continue;
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) s[e][kb] = TR::mfma(kf[ks], qf[e][ks], s[e][kb]);
+          for (int e = 0; e < RB; ++e) s[e][kb] = TR::mfma(kf, qf[e][ks], s[e][kb]);
         }
-      }
 
       // online softmax per row block; P stays in registers as the B operand of the second product
       frag pf[RB];
 #pragma unroll
       for (int e = 0; e < RB; ++e) {
-        s16x8 pk = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (need[e][0] || need[e][1]) {
-          float x[8];
+        float x[8];
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
-            if (need[e][kb]) {
+        for (int c = 0; c < 8; ++c) x[c] = s[e][c >> 2][c & 3] * p.scale_log2;
+        if constexpr (HAS_BIAS) {
+          const int pos_i = pos0 + w_row0 + 16 * e + qi;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) x[kb * 4 + r] = s[e][kb][r] * p.scale_log2;
-              if constexpr (HAS_BIAS) {
-                const int pos_i = i_min[e] + qi;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const int j = j0 + 16 * kb + koff_lane + r;
-                  if (row_valid[e] && j < p.bias_cols && pos_i < p.bias_rows && j <= key_hi[e])
-                    x[kb * 4 + r] += kLog2e * load_bias(p.bias, p.bias_dtype, (long long)pos_i * p.bias_stride + j);
-                }
-              }
-              if (!full[e]) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const int j = j0 + 16 * kb + koff_lane + r;
-                  const bool in_hole = (unsigned)(j - hole_lo - 1) < hole_width[e];
-                  x[kb * 4 + r] = (j <= key_hi[e] && !in_hole) ? x[kb * 4 + r] : -__builtin_inff();
-                }
-              }
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) x[kb * 4 + r] = -__builtin_inff();
-            }
-          }
-          float tmax = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
-          tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-          tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-          const float m_new = fmaxf(m_run[e], tmax);
-          // alpha rescales what was accumulated under the old maximum; nothing was while m_run is -inf
-          float alpha = 1.f, m_safe = 0.f;
-          if (m_new != -__builtin_inff()) {
-            m_safe = m_new;
-            if (m_run[e] != -__builtin_inff()) alpha = __builtin_amdgcn_exp2f(m_run[e] - m_new);
-          }
-          m_run[e] = m_new;
-          float psum = 0.f;
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
-            if (!need[e][kb]) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float pe = __builtin_amdgcn_exp2f(x[kb * 4 + r] - m_safe);
-              psum += pe;
-              pk[kb * 4 + r] = TR::cvt(pe);
-            }
-          }
-          l_run[e] = l_run[e] * alpha + psum;
-          if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // wave-uniform: some row's maximum moved
-#pragma unroll
-            for (int db = 0; db < DB; ++db) acc[e][db] *= alpha;
+          for (int c = 0; c < 8; ++c) {
+            const int j = j0 + 16 * (c >> 2) + koff_lane + (c & 3);
+            if (row_valid[e] && j < p.bias_cols && pos_i < p.bias_rows && j <= key_hi[e])
+              x[c] += kLog2e * load_bias(p.bias, p.bias_dtype, (long long)pos_i * p.bias_stride + j);
           }
         }
+        if (!full) {
+          const int jl = j0 + koff_lane;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const int j = jl + 16 * (c >> 2) + (c & 3);
+            const bool in_hole = (unsigned)(j - hole_lo - 1) < hole_width[e];
+            x[c] = (j <= key_hi[e] && !in_hole) ? x[c] : -__builtin_inff();
+          }
+        }
+        float tmax = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run[e], tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[e] - m_new);
+        m_run[e] = m_new;
+        float psum = 0.f;
+        s16x8 pk;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float pe = __builtin_amdgcn_exp2f(x[c] - m_new);
+          psum += pe;
+          pk[c] = TR::cvt(pe);
+        }
+        l_run[e] = l_run[e] * alpha + psum;
         pf[e] = __builtin_bit_cast(frag, pk);
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // wave-uniform: some row's maximum moved
+#pragma unroll
+          for (int db = 0; db < DB; ++db) acc[e][db] *= alpha;
+        }
       }
 
       // O^T += V^T P^T (V fragments are read once, transposed by the LDS read)
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        const int so = v_base + 32 * (db ^ v_x);
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(es + so));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(es + v_off[db]));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(es + 16 * ROWB + so));
+            (__attribute__((address_space(3))) s16x4*)(es + 16 * ROWB + v_off[db]));
         const frag vf = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
         for (int e = 0; e < RB; ++e) acc[e][db] = TR::mfma(vf, pf[e], acc[e][db]);
@@ -573,11 +585,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     for (int e = 0; e < RB; ++e) {
       float l_tot = l_run[e] + __shfl_xor(l_run[e], 16, 64);
       l_tot += __shfl_xor(l_tot, 32, 64);
-      const int my_row = 16 * (rbw + e) + qi;
-      if (!has_rows[e]) continue;  // wave-uniform
-      if (cu.slot >= 0) {
+      const int my_row = w_row0 + 16 * e + qi;
+      if (w_row0 + 16 * e >= rows_valid) continue;  // wave-uniform: the row block is past the request
+      if (slot >= 0) {
         // piece of a split q-block: unnormalised fp32 accumulator + (max, sum) for the combine pass
-        const long long prow = ((long long)cu.slot * p.H + head) * p.block_m + my_row;
+        const long long prow = ((long long)slot * p.H + head) * p.block_m + my_row;
         float* po = p.partial_o + prow * D + 4 * g;
         if (row_valid[e]) {
 #pragma unroll
@@ -590,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         continue;
       }
       const float inv = 1.0f / l_tot;  // a fully masked row gives 0 * inf = NaN, as softmax over all -inf does
-      const long long orow = (long long)(cu.q_tok0 + my_row) * p.out_stride_t + (long long)head * p.out_stride_h;
+      const long long orow = (long long)(q_tok0 + my_row) * p.out_stride_t + (long long)head * p.out_stride_h;
       if (p.out_dtype == TMX_F32) {
         float* po = reinterpret_cast<float*>(p.out) + orow + 4 * g;
         if (row_valid[e]) {
@@ -626,9 +638,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     TMX_STAMP(ts1);
     TMX_SEG(4, ts0, ts1);
 
-    cu = cu_next;
+    ca0 = cb0;
+    ca1 = cb1;
+    c_valid = cb_valid;
     ++ck;
-    cu_next = load_unit(ck + 1);
+    cb_valid = fetch_item(ck + 1, cb0, cb1);
     TMX_STAMP(ts2);
     TMX_SEG(5, ts1, ts2);
   }
