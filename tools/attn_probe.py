@@ -45,7 +45,7 @@ def timed(fn, iters):
 bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
 algo = 2 * (H + Hkv) * D * 2 * n
 for name, (si, sl_, last), mode in (("triangle(4,32,64)", (4, 32, 64), "triangle"), ("stream only (last=0)", (4, 32, 0), "triangle"),
-                                     ("window only (si=-1,last=0)", (-1, 32, 0), "triangle"), ("causal", (0, 0, 0), "causal")):
+                                     ("window only (si=-1,last=0)", (-1, 32, 0), "triangle"), ("diag+strip (si=-1,sl=0)", (-1, 0, 64), "triangle"), ("diag only (si=-1,sl=0,last=0)", (-1, 0, 0), "triangle"), ("causal", (0, 0, 0), "causal")):
     for chunk in [int(c) for c in args.chunks.split(",")]:
         if mode == "causal" and n > 16384 and args.iters > 3:
             iters = 3

@@ -131,17 +131,16 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-// s_waitcnt takes an immediate: wait until at most n (rounded down to even, capped at 2 * HI) of this
-// wave's vector-memory operations are outstanding.  Waiting for fewer than asked is always safe.
-template <int LO, int HI>
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-  if constexpr (LO == HI) {
-    wait_vmcnt<2 * LO>();
-  } else {
-    constexpr int MID = (LO + HI + 1) / 2;
-    if (n >= 2 * MID) wait_vmcnt_dyn<MID, HI>(n);
-    else wait_vmcnt_dyn<LO, MID - 1>(n);
-  }
+// s_waitcnt takes an immediate: wait until at most `n` of this wave's vector-memory operations are
+// outstanding, rounded DOWN to a multiple of STEP and capped at 4 * STEP (waiting for fewer than
+// asked is always safe).  The common steady-state value is tested first.
+template <int STEP>
+__device__ __forceinline__ void wait_vmcnt_levels(int n) {
+  if (n >= 2 * STEP && n < 3 * STEP) wait_vmcnt<2 * STEP>();
+  else if (n >= 4 * STEP) wait_vmcnt<4 * STEP>();
+  else if (n >= 3 * STEP) wait_vmcnt<3 * STEP>();
+  else if (n >= STEP) wait_vmcnt<STEP>();
+  else wait_vmcnt<0>();
 }
 
 // One LDS-DMA instruction: every lane fetches 16 bytes from its own global
@@ -194,6 +193,9 @@ __device__ __forceinline__ void glds16_s(const void* sbase, int voff, unsigned l
 // Running maximum before any key was seen: finite, so that exp2(m_old - m_new) and exp2(-inf - m)
 // need no special cases (scores are finite; a fully masked row still ends with sum 0 -> NaN).
 constexpr float kMinusBig = -1.0e30f;
+
+// Key tiles consumed per synchronisation step (wait + barrier + refill) of the attention kernel.
+constexpr int kTilesPerStep = 2;
 
 // Persistent, software-pipelined kernel.  Every workgroup walks work items
 // item0, item0 + step, ... for ONE K/V head chunk and streams their inputs
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     if (i_valid) i_krow0 = sload(p.cu_k + ia1.x);
   }
 #pragma unroll 1
-  for (int x = 0; x < NS - 1; ++x)
+  for (int x = 0; x < NS; ++x)
     if (i_valid) issue_one();
 
   // ------------------------------------------------------------------ compute side
@@ -410,15 +412,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   const unsigned long long t_begin = ts4;
 #endif
 
-  // Wait for ring entry gs, make it visible to the workgroup, refill the slot freed one step ago.
-  auto step_sync = [&]() {
+  // Wait for ring entries gs .. gs + cnt - 1, make them visible to the workgroup, then refill the
+  // slots the previous step freed (entries below gs are consumed once every wave is past the barrier).
+  auto step_sync = [&](int cnt) {
     TMX_STAMP(ts0);
-    const int younger = DPT * (gi - gs - 1) + (gs < store_mark ? store_ops : 0);
-    wait_vmcnt_dyn<0, 15>(younger);
+    wait_vmcnt_levels<DPT>(DPT * (gi - gs - cnt) + (gs + cnt - 1 < store_mark ? store_ops : 0));
     TMX_STAMP(ts1);
+#ifndef TMX_ABLATE_BARRIER
     __builtin_amdgcn_s_barrier();
+#endif
     TMX_STAMP(ts2);
-    if (i_valid) issue_one();
+#pragma unroll 1
+    while (i_valid && gi - gs < NS) issue_one();
     TMX_STAMP(ts3);
     TMX_SEG(0, ts0, ts1);
     TMX_SEG(1, ts1, ts2);
@@ -433,15 +438,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 
     // ---- Q fragments of this wave's RB row blocks (B operand of S^T) ----
     frag qf[RB][KS];
+    step_sync(RB);
 #pragma unroll
     for (int e = 0; e < RB; ++e) {
-      step_sync();
-      const char* qs = lds + ((unsigned)gs & (NS - 1)) * ENTRY + wave * (ENTRY / 4);
-      ++gs;
+      const char* qs = lds + ((unsigned)(gs + e) & (NS - 1)) * ENTRY + wave * (ENTRY / 4);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         qf[e][ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(qs + k_off[ks]));
     }
+    gs += RB;
 
     // ---- wave-uniform row range of the wave's 16 * RB rows, per-lane form of the predicate ----
     // key j is attended by this lane's row iff j <= key_hi and not (hole_lo < j < hole_lo + 1 + hole_width)
@@ -482,11 +487,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     }
 
     int tile = ntiles > 0 ? sload(p.col_idx + col_start) : 0;
+    int in_step = 0;  // entries of the current step not yet consumed
 #pragma unroll 1
     for (int t = 0; t < ntiles; ++t) {
-      step_sync();
-      const unsigned eoff = ((unsigned)gs & (NS - 1)) * ENTRY;
-      const char* es = lds + eoff;
+      if (in_step == 0) {
+        in_step = imin(kTilesPerStep, ntiles - t);
+        step_sync(in_step);
+      }
+      --in_step;
+      const char* es = lds + ((unsigned)gs & (NS - 1)) * ENTRY;
       ++gs;
       const int j0 = tile * kBlockN, j1 = j0 + kBlockN - 1;
       if (t + 1 < ntiles) tile = sload(p.col_idx + col_start + t + 1);  // for the next iteration
@@ -500,6 +509,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         full = j1 <= w_imin;
         if (mode == TMX_MODE_TRIANGLE && !w_all_last) full = full && (j1 <= p.si || j0 >= w_imax - p.sl);
       }
+#ifdef TMX_ABLATE_COMPUTE
+      if (p.scale_log2 != 12345.f) continue;
+#endif
       if (!w_has_rows) continue;
       TMX_STAMP(ts0);
 
@@ -658,53 +670,62 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 }
 
 // Merge the pieces of every split q-block: out = sum_p O_p 2^(m_p - M) / sum_p l_p 2^(m_p - M).
+// One workgroup per (split q-block, head, 8 rows): a thread owns 4 output columns of one row and
+// folds the pieces in with a running maximum, 4 pieces' loads in flight at a time.
 template <typename TR, int D>
-__global__ __launch_bounds__(256) void combine_kernel(AttnParams p) {
-  const int qb = p.split_qb[blockIdx.x];
+__global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p) {
+  constexpr int C4 = D / 4;
+  const int groups = (p.block_m + 7) / 8;
+  const int qb = p.split_qb[blockIdx.x / groups];
+  const int row = (blockIdx.x % groups) * 8 + threadIdx.x / C4;
+  const int d4 = threadIdx.x % C4;
   const int head = blockIdx.y;
   const int slot0 = p.part_ptr[qb], np = p.part_ptr[qb + 1] - slot0;
   const int b = p.qb_meta[2 * qb], row0 = p.qb_meta[2 * qb + 1];
   const int q_start = p.cu_q[b];
   const int q_len = p.cu_q[b + 1] - q_start;
-  const int rows = imin(p.block_m, q_len - row0);
-  constexpr int C4 = D / 4;
-  for (int idx = threadIdx.x; idx < rows * C4; idx += 256) {
-    const int row = idx / C4, d4 = idx - row * C4;
-    float M = -__builtin_inff();
-    for (int pc = 0; pc < np; ++pc) {
-      const int64_t prow = ((int64_t)(slot0 + pc) * p.H + head) * p.block_m + row;
-      M = fmaxf(M, p.partial_ml[prow * 2]);
+  if (row >= imin(p.block_m, q_len - row0)) return;
+  const long long stride = (long long)p.H * p.block_m;  // partial rows between consecutive pieces
+  const long long prow0 = ((long long)slot0 * p.H + head) * p.block_m + row;
+  float M = kMinusBig, l = 0.f;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int pc = 0; pc < np; pc += 4) {
+    float2 ml[4];
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long prow = prow0 + (long long)imin(pc + u, np - 1) * stride;
+      ml[u] = *reinterpret_cast<const float2*>(p.partial_ml + prow * 2);
+      v[u] = reinterpret_cast<const float4*>(p.partial_o + prow * D)[d4];
     }
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    float l = 0.f;
-    for (int pc = 0; pc < np; ++pc) {
-      const int64_t prow = ((int64_t)(slot0 + pc) * p.H + head) * p.block_m + row;
-      const float mp = p.partial_ml[prow * 2];
-      if (mp == -__builtin_inff()) continue;  // this piece saw no attended key for the row
-      const float w = __builtin_amdgcn_exp2f(mp - M);
-      l += w * p.partial_ml[prow * 2 + 1];
-      const float4 v = reinterpret_cast<const float4*>(p.partial_o + prow * D)[d4];
-      o.x += w * v.x;
-      o.y += w * v.y;
-      o.z += w * v.z;
-      o.w += w * v.w;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pc + u >= np) break;
+      const float Mn = fmaxf(M, ml[u].x);
+      const float a = __builtin_amdgcn_exp2f(M - Mn), w = __builtin_amdgcn_exp2f(ml[u].x - Mn);
+      M = Mn;
+      l = l * a + w * ml[u].y;
+      o.x = o.x * a + w * v[u].x;
+      o.y = o.y * a + w * v[u].y;
+      o.z = o.z * a + w * v[u].z;
+      o.w = o.w * a + w * v[u].w;
     }
-    const float inv = 1.0f / l;
-    o.x *= inv;
-    o.y *= inv;
-    o.z *= inv;
-    o.w *= inv;
-    const int64_t off = (long long)(q_start + row0 + row) * p.out_stride_t + (long long)head * p.out_stride_h + 4 * d4;
-    if (p.out_dtype == TMX_F32) {
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + off) = o;
-    } else {
-      s16x4 h;
-      h[0] = TR::cvt(o.x);
-      h[1] = TR::cvt(o.y);
-      h[2] = TR::cvt(o.z);
-      h[3] = TR::cvt(o.w);
-      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + off) = __builtin_bit_cast(uint2, h);
-    }
+  }
+  const float inv = 1.0f / l;  // every piece empty for this row: 0 * inf = NaN, as for an unsplit row
+  o.x *= inv;
+  o.y *= inv;
+  o.z *= inv;
+  o.w *= inv;
+  const long long off = (long long)(q_start + row0 + row) * p.out_stride_t + (long long)head * p.out_stride_h + 4 * d4;
+  if (p.out_dtype == TMX_F32) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + off) = o;
+  } else {
+    s16x4 h;
+    h[0] = TR::cvt(o.x);
+    h[1] = TR::cvt(o.y);
+    h[2] = TR::cvt(o.z);
+    h[3] = TR::cvt(o.w);
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + off) = __builtin_bit_cast(uint2, h);
   }
 }
 
@@ -750,7 +771,8 @@ static int launch(const AttnParams& p, bool paged, bool has_bias, int64_t num_sp
     if (rc != TMX_OK) return rc;
   }
   if (num_split > 0 && !(flags & TMX_ATTN_SKIP_COMBINE)) {
-    combine_kernel<TR, D><<<dim3((unsigned)num_split, (unsigned)p.H), 256, 0, s>>>(p);
+    const unsigned groups = (unsigned)((p.block_m + 7) / 8);
+    combine_kernel<TR, D><<<dim3((unsigned)num_split * groups, (unsigned)p.H), 8 * (D / 4), 0, s>>>(p);
     TMX_CHECK_HIP(hipGetLastError());
   }
   return TMX_OK;
