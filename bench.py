@@ -35,6 +35,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 QWEN3_8B = dict(num_heads=32, num_kv_heads=8, head_dim=128, hidden=4096)
 PATTERN = (4, 32, 64)  # sink, window, last: the reference defaults
 PAGE = 16
+CHUNK_TILES = 32  # key tiles per work item of the dense trailing rows (32 x 32 = 1024 keys)
 
 
 def parse():
@@ -140,8 +141,10 @@ def main():
     kc, vc = inp["kv_cache"][0], inp["kv_cache"][1]
 
     def build(mode):
+        # pages of every listed tile are resolved by the builder (block table lookups leave the attention loop)
         return ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn,
-                                     ops.MODES[mode])
+                                     ops.MODES[mode], chunk_tiles=CHUNK_TILES, block_table=inp["block_table"],
+                                     page_size=PAGE)
 
     idx0 = build("triangle")
     work = ops.alloc_workspace(idx0, H, D, dev)

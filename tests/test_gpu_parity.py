@@ -426,3 +426,79 @@ def test_reshape_and_cache_and_errors():
     q = torch.zeros((64, 4, 128), dtype=torch.bfloat16, device=DEV)
     with pytest.raises(TmxError):
         ops.attention(q, q, q, torch.empty_like(q), idx, cu, sld, 1.0, cu_seqlens_k=cu)
+
+
+# ------------------------------------------------------------------ vLLM backend surface
+def test_backend_forward_mixed_batch():
+    """TriangleMixAttentionImpl.forward on a mixed step: a long prefill (triangle), a short prefill
+    (plain causal below the 2048-token gate), a chunked-prefill continuation and a decode row; K/V
+    of the step are written through slot_mapping, earlier context is already in the paged cache."""
+    import types
+    from vllm_trianglemix_amd import TriangleMixConfig
+    from vllm_trianglemix_amd.backend import TriangleMixAttentionBackend, TriangleMixMetadataBuilder
+    H, Hkv, D, page = 8, 2, 128, 16
+    q_lens, seq_lens = [2300, 100, 64, 1], [2300, 100, 2500, 2100]
+    q, ks, vs = _rand_case(4242, q_lens, seq_lens, H, Hkv, D)
+    scale = D ** -0.5
+    cu = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    T = int(cu[-1])
+    nblk = sum((s + page - 1) // page for s in seq_lens) + 5
+    perm = np.random.default_rng(3).permutation(nblk).astype(np.int32)
+    shape = TriangleMixAttentionBackend.get_kv_cache_shape(nblk, page, Hkv, D)
+    kv_cache = torch.zeros(shape, dtype=torch.bfloat16, device=DEV)
+    maxb = max((s + page - 1) // page for s in seq_lens)
+    bt = np.zeros((len(seq_lens), maxb), np.int32)
+    slots = np.zeros((T,), np.int64)
+    k_new, v_new = np.zeros((T, Hkv, D), np.float32), np.zeros((T, Hkv, D), np.float32)
+    nxt = 0
+    for b, (ql, s) in enumerate(zip(q_lens, seq_lens)):
+        for pb in range((s + page - 1) // page):
+            bt[b, pb] = perm[nxt]
+            nxt += 1
+        ctx = s - ql
+        if ctx:  # context already cached
+            jj = np.arange(ctx)
+            blk = torch.from_numpy(bt[b, jj // page].astype(np.int64)).to(DEV)
+            off = torch.from_numpy(jj % page).to(DEV)
+            kv_cache[0, blk, off] = _to_dev(ks[b][:ctx], torch.bfloat16)
+            kv_cache[1, blk, off] = _to_dev(vs[b][:ctx], torch.bfloat16)
+        pos = np.arange(ctx, s)
+        slots[cu[b]:cu[b + 1]] = bt[b, pos // page].astype(np.int64) * page + pos % page
+        k_new[cu[b]:cu[b + 1]], v_new[cu[b]:cu[b + 1]] = ks[b][ctx:], vs[b][ctx:]
+    pad = 5  # padded tokens beyond num_actual_tokens must be left alone
+    common = types.SimpleNamespace(
+        num_actual_tokens=T, max_query_len=max(q_lens), max_seq_len=max(seq_lens),
+        query_start_loc=torch.from_numpy(cu).to(DEV), query_start_loc_cpu=torch.from_numpy(cu),
+        seq_lens=torch.tensor(seq_lens, dtype=torch.int32, device=DEV),
+        seq_lens_cpu=torch.tensor(seq_lens, dtype=torch.int32),
+        block_table_tensor=torch.from_numpy(bt).to(DEV), slot_mapping=torch.from_numpy(slots).to(DEV))
+    builder = TriangleMixAttentionBackend.get_builder_cls()(types.SimpleNamespace(block_size=page), ["l0", "l1"],
+                                                            None, torch.device(DEV))
+    assert isinstance(builder, TriangleMixMetadataBuilder)
+    md = builder.build(0, common)
+    cfg = TriangleMixConfig(num_triangle_layers=1)
+    impl_cls = TriangleMixAttentionBackend.get_impl_cls()
+    qd = torch.zeros((T + pad, H, D), dtype=torch.bfloat16, device=DEV)
+    qd[:T] = _to_dev(q, torch.bfloat16)
+    kd = torch.zeros((T + pad, Hkv, D), dtype=torch.bfloat16, device=DEV)
+    vd = torch.zeros_like(kd)
+    kd[:T], vd[:T] = _to_dev(k_new, torch.bfloat16), _to_dev(v_new, torch.bfloat16)
+    for layer_idx, tri in ((0, True), (1, False)):
+        impl = impl_cls(H, D, scale, Hkv, None, None, "auto", None, "decoder", None, trianglemix_config=cfg,
+                        layer_idx=layer_idx)
+        assert impl.use_triangle is tri
+        out = torch.full((T + pad, H * D), 3.0, dtype=torch.bfloat16, device=DEV)
+        ret = impl.forward(None, qd, kd, vd, kv_cache, md, output=out)
+        assert ret is out
+        torch.cuda.synchronize()
+        got = out.float().cpu().numpy().reshape(T + pad, H, D)
+        assert np.all(got[T:] == 3.0)
+        ref = np.zeros((T, H, D))
+        for b, (ql, s) in enumerate(zip(q_lens, seq_lens)):
+            mode = "triangle" if (tri and s > 2048) else "causal"
+            ref[cu[b]:cu[b + 1]] = orc.varlen_gqa_attention(q[cu[b]:cu[b + 1]], lambda _: ks[b], lambda _: vs[b],
+                                                            [0, ql], [s], scale, mode, 4, 32, 64)
+        err = np.abs(got[:T] - ref)
+        assert np.all(err <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8), (layer_idx, err.max())
+    # both layers asked for different modes: two indices were built and cached on the step's metadata
+    assert len(md._indices) == 2

@@ -1,0 +1,250 @@
+"""CPU tests (no GPU): the package's host logic against the golden fixtures,
+the C-ABI library's symbol table against the header, the host-side index sizing
+against the oracle, and the loud failure of the product path without a device.
+No compute entry point of the library is called here."""
+import ctypes
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import trianglemix_oracle as orc
+from vllm_trianglemix_amd import (AscendTriangleMixAttention, TriangleMixAnalyzer, TriangleMixAttention,
+                                  TriangleMixConfig, TriangleMixInferenceConfig, TriangleMixMaskGenerator,
+                                  create_trianglemix_config_from_hf, _lib, ops)
+from vllm_trianglemix_amd.backend import (TriangleMixAttentionBackend, TriangleMixAttentionImpl,
+                                          TriangleMixMetadataBuilder)
+from vllm_trianglemix_amd.parallel import shard_heads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "trianglemix_hip.h")
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(tmx_[a-z0-9_]+)\s*\(", text)))
+    assert declared, "no declarations found in the header"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared
+    lib = _lib.load()  # raises if the library is missing: there is no fallback
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared but not exported"
+    assert lib.tmx_abi_version() == _lib.TMX_ABI_VERSION
+    assert lib.tmx_attention_block_n() == 32
+
+
+def test_struct_layouts_match_the_header():
+    """The ctypes mirrors must have the sizes the C compiler gives the header's structs."""
+    import subprocess, tempfile
+    src = ('#include <stdio.h>\n#include "trianglemix_hip.h"\n'
+           'int main(void){printf("%zu %zu %zu\\n", sizeof(tmx_index_sizes_t), sizeof(tmx_index_t), '
+           'sizeof(tmx_attention_args_t));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "s.c"), os.path.join(d, "s")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        sizes = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(_lib.IndexSizes), ctypes.sizeof(_lib.Index), ctypes.sizeof(_lib.AttentionArgs)]
+
+
+@pytest.mark.parametrize("heads,kv,bm", [(32, 8, 32), (16, 8, 64), (8, 8, 128), (64, 8, 32), (4, 1, 32), (6, 2, 128)])
+def test_block_m_rule(heads, kv, bm):
+    assert ops.attention_block_m(heads, kv) == bm
+    with pytest.raises(RuntimeError):
+        ops.attention_block_m(7, 2)
+
+
+# ------------------------------------------------------------------ index sizing (host-only entry point)
+@pytest.mark.parametrize("mode", ["none", "causal", "triangle"])
+@pytest.mark.parametrize("chunk", [2, 64])
+def test_index_sizes_match_oracle(mode, chunk):
+    rng = np.random.default_rng(7)
+    for _ in range(6):
+        batch = int(rng.integers(1, 5))
+        seq = rng.integers(1, 700, size=batch)
+        qlen = np.asarray([int(rng.integers(1, s + 1)) for s in seq])
+        si, sl, last = int(rng.integers(0, 9)), int(rng.integers(0, 70)), int(rng.integers(0, 90))
+        bm, bn, m = 32, 32, ops.MODES[mode]
+        cu = np.concatenate([[0], np.cumsum(qlen)]).astype(np.int32)
+        sz = ops.index_sizes(cu, seq.astype(np.int32), si, sl, last, bm, bn, m, chunk_tiles=chunk)
+        row_ptr, col_idx, qb_seq, qb_row0 = orc.block_index_closed_form(qlen, seq, si, sl, last, bm, bn, m)
+        items, part_ptr = orc.work_items(row_ptr, chunk)
+        assert sz.num_qblocks == len(row_ptr) - 1
+        assert sz.nnz_tiles == len(col_idx)
+        assert sz.num_items == len(items)
+        assert sz.num_partials == int(part_ptr[-1])
+        assert sz.num_split_qblocks == int(np.count_nonzero(np.diff(part_ptr)))
+        assert sz.max_tiles_per_qblock == int(np.max(np.diff(row_ptr)))
+
+
+def test_index_sizes_rejects_bad_input():
+    with pytest.raises(RuntimeError):
+        ops.index_sizes([0, 5, 9], [5], 4, 32, 64, 32, 32, ops.MODES["triangle"])
+    with pytest.raises(_lib.TmxError):  # query longer than its sequence
+        ops.index_sizes([0, 9], [5], 4, 32, 64, 32, 32, ops.MODES["triangle"])
+
+
+# ------------------------------------------------------------------ configuration and layer selection
+def test_should_use_triangle_tables(golden_selection):
+    for case in golden_selection["should_use_triangle"]:
+        cfg = TriangleMixConfig(num_triangle_layers=case["num_triangle_layers"],
+                                triangle_layer_indices=case["triangle_layer_indices"])
+        gen = TriangleMixMaskGenerator(cfg)
+        assert [gen.should_use_triangle(i) for i in range(len(case["table"]))] == case["table"]
+        assert [cfg.uses_triangle(i) for i in range(len(case["table"]))] == case["table"]
+
+
+def test_helper_decisions(golden_selection):
+    for case in golden_selection["helper"]:
+        cfg = TriangleMixConfig(num_triangle_layers=case["num_triangle_layers"],
+                                triangle_layer_indices=case["triangle_layer_indices"])
+        helper = TriangleMixAttention(cfg, num_layers=case["num_layers"])
+        assert list(cfg.triangle_layer_indices) == case["indices_after_init"]  # the shared config is filled in place
+        for d in case["decisions"]:
+            assert helper.mask_kind(d["n"], d["layer"]) == d["kind"], d
+
+
+def test_presets(golden_selection):
+    p = golden_selection["presets"]
+
+    def tm(cfg):
+        t = cfg.to_trianglemix_config()
+        return [t.num_sink_tokens, t.sliding_window_size, t.num_last_tokens, t.num_triangle_layers,
+                list(t.triangle_layer_indices)]
+
+    for size in ("14B", "32B", "8B"):
+        want = p[f"for_qwen3_{size}"]
+        cfg = TriangleMixInferenceConfig.for_qwen3(size)
+        for k, v in want.items():
+            assert (tm(cfg) if k == "tm_cfg" else getattr(cfg, k)) == v, (size, k)
+    assert TriangleMixInferenceConfig.for_qwen3("14B", 3).num_triangle_layers == \
+        p["for_qwen3_14B_override3"]["num_triangle_layers"]
+    a = TriangleMixInferenceConfig.for_ascend_npu()
+    for k, v in p["for_ascend_npu"].items():
+        assert getattr(a, k) == v
+    d = TriangleMixInferenceConfig()
+    assert d.enable_trianglemix is False and d.to_trianglemix_config() is None and d.triangle_layer_indices == []
+    c = TriangleMixInferenceConfig(enable_trianglemix=True, triangle_layer_indices=[0, 1, 2])
+    assert tm(c) == p["custom_indices"]["tm_cfg"]
+
+
+def test_config_from_hf(golden_selection):
+    for case in golden_selection["from_hf"]:
+        hf = types.SimpleNamespace(**case["attrs"])
+        cfg = create_trianglemix_config_from_hf(hf, use_trianglemix=case["use"], num_triangle_layers=case["ntl"])
+        if case["result"] is None:
+            assert cfg is None
+        else:
+            assert [cfg.num_sink_tokens, cfg.sliding_window_size, cfg.num_last_tokens, cfg.num_triangle_layers,
+                    list(cfg.triangle_layer_indices)] == case["result"]
+    with pytest.raises(TypeError):  # a config whose sliding_window is None fails as in the reference
+        create_trianglemix_config_from_hf(types.SimpleNamespace(sliding_window=None), use_trianglemix=True)
+
+
+def test_analyzer(golden_selection):
+    for case in golden_selection["analyzer"]:
+        an = TriangleMixAnalyzer(num_layers=len(case["grads"]))
+        for layer, grads in enumerate(case["grads"]):
+            for gval in grads:
+                an.record_middle_qk_gradient(layer, torch.tensor([gval, gval]))
+        assert an.get_triangle_layers(case["k"]) == case["layers"]
+
+
+# ------------------------------------------------------------------ no CPU fallback
+def test_product_path_refuses_cpu_tensors():
+    gen = TriangleMixMaskGenerator(TriangleMixConfig())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gen._create_streaming_mask(8, torch.device("cpu"), torch.float32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gen.get_attention_mask(8, 0, torch.device("cpu"), torch.float32)
+    attn = AscendTriangleMixAttention(num_heads=2, head_dim=64, scale=0.125)
+    x = torch.zeros((1, 8, 2, 64), dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        attn(x, x, x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.reshape_and_cache(torch.zeros(1, 1, 64), torch.zeros(1, 1, 64), torch.zeros(1, 16, 1, 64),
+                              torch.zeros(1, 16, 1, 64), torch.zeros(1, dtype=torch.int64))
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtrianglemix_hip.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+# ------------------------------------------------------------------ backend surface
+def test_backend_surface():
+    b = TriangleMixAttentionBackend
+    assert b.accept_output_buffer is True
+    assert b.get_name() == "TRIANGLEMIX_ROCM"
+    assert b.get_impl_cls() is TriangleMixAttentionImpl and b.get_builder_cls() is TriangleMixMetadataBuilder
+    assert b.get_kv_cache_shape(10, 16, 8, 128) == (2, 10, 16, 8, 128)
+    with pytest.raises(ValueError):
+        b.get_kv_cache_shape(10, 24, 8, 128)
+    assert set(b.get_supported_dtypes()) == {torch.float16, torch.bfloat16}
+    b.validate_head_size(128)
+    with pytest.raises(ValueError):
+        b.validate_head_size(96)
+
+
+def test_impl_constructor_rules():
+    cfg = TriangleMixConfig(num_triangle_layers=2)
+    on = TriangleMixAttentionImpl(32, 128, 0.088, 8, None, None, "auto", None, "decoder", None,
+                                  trianglemix_config=cfg, layer_idx=1)
+    off = TriangleMixAttentionImpl(32, 128, 0.088, 8, None, None, "auto", trianglemix_config=cfg, layer_idx=2)
+    assert on.use_triangle and not off.use_triangle and on.pattern == (4, 32, 64) and on.tri_min_len == 2049
+    flag = TriangleMixAttentionImpl(16, 64, 0.125, 8, None, None, "auto", use_triangle=True, num_sink_tokens=2,
+                                    sliding_window_size=8, num_last_tokens=16)
+    assert flag.use_triangle and flag.pattern == (2, 8, 16)
+    for bad in (dict(alibi_slopes=[0.5]), dict(sliding_window=128), dict(logits_soft_cap=30.0),
+                dict(kv_cache_dtype="fp8"), dict(attn_type="encoder")):
+        kw = dict(num_heads=32, head_size=128, scale=0.088, num_kv_heads=8)
+        kw.update(bad)
+        with pytest.raises(NotImplementedError):
+            TriangleMixAttentionImpl(**kw)
+    with pytest.raises(ValueError):
+        TriangleMixAttentionImpl(32, 96, 0.1, 8)
+    # profiling run: no metadata -> output untouched
+    out = torch.full((4, 32 * 128), 7.0)
+    assert on.forward(None, None, None, None, None, None, output=out) is out and bool((out == 7.0).all())
+
+
+def test_metadata_builder_copies_host_description():
+    spec = types.SimpleNamespace(block_size=16)
+    builder = TriangleMixMetadataBuilder(spec, ["layers.0.attn"], None, torch.device("cpu"))
+    common = types.SimpleNamespace(
+        num_actual_tokens=7, max_query_len=4, max_seq_len=9,
+        query_start_loc=torch.tensor([0, 3, 7], dtype=torch.int32), query_start_loc_cpu=torch.tensor([0, 3, 7], dtype=torch.int32),
+        seq_lens=torch.tensor([9, 4], dtype=torch.int32), seq_lens_cpu=torch.tensor([9, 4], dtype=torch.int32),
+        block_table_tensor=torch.zeros((2, 4), dtype=torch.int32), slot_mapping=torch.arange(7, dtype=torch.int64))
+    md = builder.build(0, common)
+    assert md.page_size == 16 and md.num_actual_tokens == 7
+    assert md.query_start_loc_cpu.dtype == np.int32 and md.query_start_loc_cpu.tolist() == [0, 3, 7]
+    assert md.seq_lens_cpu.tolist() == [9, 4]
+    with pytest.raises(NotImplementedError):
+        builder.build(5, common)
+
+
+# ------------------------------------------------------------------ head sharding rule
+def test_shard_heads_rule():
+    # K/V heads partitioned while there are enough of them, replicated beyond (one K/V head per rank)
+    for world in (1, 2, 4, 8):
+        shards = [shard_heads(32, 8, r, world) for r in range(world)]
+        assert sum(s.num_heads for s in shards) == 32
+        assert [s.head_start for s in shards] == [r * 32 // world for r in range(world)]
+        assert all(s.num_kv_heads == 8 // world and not s.kv_replicated for s in shards)
+        for s in shards:  # every local query head finds its K/V head inside the local K/V slice
+            for h in range(s.head_start, s.head_start + s.num_heads):
+                assert s.kv_head_start <= h // 4 < s.kv_head_start + s.num_kv_heads
+    s = [shard_heads(64, 8, r, 16) for r in range(16)]
+    assert all(x.num_kv_heads == 1 and x.kv_replicated for x in s)
+    assert [x.kv_head_start for x in s] == [r // 2 for r in range(16)]
+    with pytest.raises(ValueError):
+        shard_heads(30, 8, 0, 4)
+    with pytest.raises(ValueError):
+        shard_heads(32, 8, 0, 3)

@@ -9,9 +9,13 @@ from .config import (TriangleMixConfig, TriangleMixInferenceConfig,  # noqa: F40
 from .mask_generator import (TriangleMixAnalyzer, TriangleMixAttention,  # noqa: F401
                              TriangleMixMaskGenerator)
 from .eager_attention import AscendNPUTriangleMixOptimizer, AscendTriangleMixAttention  # noqa: F401
+from .backend import (TriangleMixAttentionBackend, TriangleMixAttentionImpl,  # noqa: F401
+                      TriangleMixAttentionMetadata, TriangleMixMetadataBuilder)
 
 __all__ = [
     "TriangleMixConfig", "TriangleMixInferenceConfig", "create_trianglemix_config_from_hf",
     "TriangleMixMaskGenerator", "TriangleMixAttention", "TriangleMixAnalyzer",
     "AscendTriangleMixAttention", "AscendNPUTriangleMixOptimizer",
+    "TriangleMixAttentionBackend", "TriangleMixAttentionImpl", "TriangleMixAttentionMetadata",
+    "TriangleMixMetadataBuilder",
 ]

@@ -1,0 +1,251 @@
+"""vLLM v1 attention-backend surface for the TriangleMix path on MI355X.
+
+Mirrors the three classes a vLLM backend provides -- the reference's own ROCm
+backend is the model (vllm/v1/attention/backends/rocm_attn.py:31-426, abstract
+interfaces vllm/attention/backends/abstract.py:27-182, builder interface
+vllm/v1/attention/backends/utils.py:232-341):
+
+* ``TriangleMixAttentionBackend``  -- names, KV-cache shape, supported dtypes / head sizes;
+* ``TriangleMixMetadataBuilder``   -- turns the per-step ``CommonAttentionMetadata`` into the
+  per-step metadata; the block-sparse index is built once per step and shared by all layers;
+* ``TriangleMixAttentionImpl``     -- ``forward(layer, query, key, value, kv_cache,
+  attn_metadata, output)``: KV-cache write, then masked attention, in place into ``output``.
+
+When vLLM is importable the classes derive from its abstract bases so that
+``Attention(..., attn_backend=TriangleMixAttentionBackend)`` (vllm/attention/layer.py:102,
+186-201) accepts them; otherwise small stand-ins with the same members are used.
+Everything here is host logic; the compute is the HIP library (no CPU fallback).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import ClassVar, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import SHORT_SEQUENCE_GATE, TriangleMixConfig
+
+try:  # pragma: no cover - depends on the host installation
+    from vllm.attention.backends.abstract import AttentionBackend as _BackendBase
+    from vllm.attention.backends.abstract import AttentionImpl as _ImplBase
+    from vllm.attention.backends.abstract import AttentionType as _AttentionType
+    _DECODER = _AttentionType.DECODER
+except Exception:  # vLLM (or one of its dependencies) is not installed
+    class _BackendBase:  # the members vllm/attention/backends/abstract.py:27-83 declares
+        accept_output_buffer: bool = False
+
+    class _ImplBase:
+        pass
+
+    _DECODER = "decoder"  # vllm/attention/backends/abstract.py:17-24
+
+
+@dataclass
+class TriangleMixAttentionMetadata:
+    """Per-step metadata (the fields rocm_attn.py:31-57 carries, plus the host copies the
+    index sizing needs and the per-step index cache)."""
+    num_actual_tokens: int
+    max_query_len: int
+    query_start_loc: torch.Tensor      # int32 [B + 1], device
+    max_seq_len: int
+    seq_lens: torch.Tensor             # int32 [B], device
+    block_table: torch.Tensor          # int32 [B, max_blocks], device
+    slot_mapping: torch.Tensor         # int64 [T], device
+    query_start_loc_cpu: np.ndarray    # int32 [B + 1]
+    seq_lens_cpu: np.ndarray           # int32 [B]
+    page_size: int
+    use_cascade: bool = False
+    common_prefix_len: int = 0
+    _indices: Dict[Tuple, "ops.BlockIndex"] = field(default_factory=dict, repr=False)
+    _workspaces: Dict[Tuple, tuple] = field(default_factory=dict, repr=False)
+
+    def block_index(self, mode: str, pattern: Tuple[int, int, int], num_heads: int, num_kv_heads: int,
+                    tri_min_len: int) -> "ops.BlockIndex":
+        """The step's index for (mode, pattern, head grouping): built on first use, then
+        shared by every layer that asks for the same one (the mask does not depend on the layer
+        beyond the triangle/dense choice)."""
+        block_m = ops.attention_block_m(num_heads, num_kv_heads)
+        key = (mode, pattern, block_m, tri_min_len)
+        idx = self._indices.get(key)
+        if idx is None:
+            idx = ops.build_block_index(self.query_start_loc, self.seq_lens, self.query_start_loc_cpu,
+                                        self.seq_lens_cpu, pattern[0], pattern[1], pattern[2], block_m,
+                                        ops.attention_block_n(), ops.MODES[mode], tri_min_len=tri_min_len,
+                                        block_table=self.block_table, page_size=self.page_size)
+            self._indices[key] = idx
+        return idx
+
+    def workspace(self, idx: "ops.BlockIndex", num_heads: int, head_size: int, device) -> tuple:
+        key = (id(idx), num_heads, head_size)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            ws = ops.alloc_workspace(idx, num_heads, head_size, device)
+            self._workspaces[key] = ws
+        return ws
+
+
+class TriangleMixMetadataBuilder:
+    """``AttentionMetadataBuilder`` counterpart (utils.py:232-341; rocm_attn.py:60-135)."""
+    cudagraph_support: ClassVar[str] = "NEVER"   # the index depends on the batch: rebuilt every step
+    reorder_batch_threshold: ClassVar[Optional[int]] = None
+
+    def __init__(self, kv_cache_spec, layer_names: List[str], vllm_config, device: torch.device):
+        self.kv_cache_spec = kv_cache_spec
+        self.layer_names = layer_names
+        self.vllm_config = vllm_config
+        self.device = device
+        self.block_size = int(kv_cache_spec.block_size)
+
+    def build(self, common_prefix_len: int, common_attn_metadata, fast_build: bool = False
+              ) -> TriangleMixAttentionMetadata:
+        m = common_attn_metadata
+        if common_prefix_len > 0:
+            raise NotImplementedError("cascade attention (a shared prefix pass) is not part of the TriangleMix path")
+
+        def host_i32(t):
+            return np.ascontiguousarray(t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t), dtype=np.int32)
+
+        return TriangleMixAttentionMetadata(
+            num_actual_tokens=int(m.num_actual_tokens), max_query_len=int(m.max_query_len),
+            query_start_loc=m.query_start_loc, max_seq_len=int(m.max_seq_len), seq_lens=m.seq_lens,
+            block_table=m.block_table_tensor, slot_mapping=m.slot_mapping,
+            query_start_loc_cpu=host_i32(m.query_start_loc_cpu), seq_lens_cpu=host_i32(m.seq_lens_cpu),
+            page_size=self.block_size)
+
+    def build_for_cudagraph_capture(self, common_attn_metadata) -> TriangleMixAttentionMetadata:
+        return self.build(0, common_attn_metadata)
+
+    def use_cascade_attention(self, *args, **kwargs) -> bool:
+        return False
+
+
+class TriangleMixAttentionBackend(_BackendBase):
+    accept_output_buffer: bool = True  # abstract.py:32, rocm_attn.py:139
+
+    @classmethod
+    def get_supported_dtypes(cls) -> List[torch.dtype]:
+        return [torch.float16, torch.bfloat16]
+
+    @classmethod
+    def get_supported_head_sizes(cls) -> List[int]:
+        return [64, 128]
+
+    @classmethod
+    def validate_head_size(cls, head_size: int) -> None:
+        supported = cls.get_supported_head_sizes()
+        if head_size not in supported:
+            raise ValueError(f"Head size {head_size} is not supported by TriangleMixAttention. "
+                             f"Supported head sizes are: {supported}.")
+
+    @staticmethod
+    def get_name() -> str:
+        return "TRIANGLEMIX_ROCM"
+
+    @staticmethod
+    def get_impl_cls():
+        return TriangleMixAttentionImpl
+
+    @staticmethod
+    def get_metadata_cls():
+        return TriangleMixAttentionMetadata
+
+    @staticmethod
+    def get_builder_cls():
+        return TriangleMixMetadataBuilder
+
+    @staticmethod
+    def get_kv_cache_shape(num_blocks: int, block_size: int, num_kv_heads: int, head_size: int,
+                           cache_dtype_str: str = "auto") -> Tuple[int, ...]:
+        # same layout as rocm_attn.py:173-181; pages must be a power of two of at least 16 tokens
+        if block_size < 16 or block_size & (block_size - 1):
+            raise ValueError("Block size must be a power of two of at least 16.")
+        return (2, num_blocks, block_size, num_kv_heads, head_size)
+
+    @staticmethod
+    def use_cascade_attention(*args, **kwargs) -> bool:
+        return False
+
+
+class TriangleMixAttentionImpl(_ImplBase):
+    """Positional arguments as vllm/attention/layer.py:198-201 passes them; the TriangleMix
+    settings arrive through ``**extra_impl_args`` (layer.py:103): either a ``trianglemix_config``
+    + ``layer_idx`` (the layer decides with ``should_use_triangle``,
+    trianglemix_attention.py:263-278) or an explicit ``use_triangle`` flag + pattern."""
+
+    def __init__(self, num_heads: int, head_size: int, scale: float, num_kv_heads: Optional[int] = None,
+                 alibi_slopes: Optional[List[float]] = None, sliding_window: Optional[int] = None,
+                 kv_cache_dtype: str = "auto", logits_soft_cap: Optional[float] = None,
+                 attn_type=_DECODER, kv_sharing_target_layer_name: Optional[str] = None, *,
+                 trianglemix_config: Optional[TriangleMixConfig] = None, layer_idx: Optional[int] = None,
+                 use_triangle: Optional[bool] = None, num_sink_tokens: Optional[int] = None,
+                 sliding_window_size: Optional[int] = None, num_last_tokens: Optional[int] = None,
+                 short_sequence_gate: int = SHORT_SEQUENCE_GATE, **unused) -> None:
+        self.num_heads = num_heads
+        self.head_size = head_size
+        self.scale = float(scale)
+        self.num_kv_heads = num_heads if num_kv_heads is None else num_kv_heads
+        self.kv_cache_dtype = kv_cache_dtype
+        self.kv_sharing_target_layer_name = kv_sharing_target_layer_name
+        TriangleMixAttentionBackend.validate_head_size(head_size)
+        if self.num_heads % self.num_kv_heads != 0:
+            raise ValueError(f"num_heads {num_heads} must be a multiple of num_kv_heads {self.num_kv_heads}")
+        if str(getattr(attn_type, "value", attn_type)) != str(getattr(_DECODER, "value", _DECODER)):
+            raise NotImplementedError("Encoder self-attention and encoder/decoder cross-attention are not "
+                                      "implemented for TriangleMixAttentionImpl")
+        if alibi_slopes is not None:
+            raise NotImplementedError("ALiBi slopes are not supported by TriangleMixAttentionImpl")
+        if sliding_window is not None:
+            raise NotImplementedError("a model-level sliding window is not supported by TriangleMixAttentionImpl "
+                                      "(the TriangleMix pattern carries its own window)")
+        if logits_soft_cap:
+            raise NotImplementedError("logits soft cap is not supported by TriangleMixAttentionImpl")
+        if kv_cache_dtype not in ("auto", "bfloat16", "float16", "half"):
+            raise NotImplementedError(f"kv_cache_dtype '{kv_cache_dtype}' is not supported (16-bit caches only)")
+
+        cfg = trianglemix_config
+        if cfg is None:
+            cfg = TriangleMixConfig()
+            if num_sink_tokens is not None:
+                cfg.num_sink_tokens = num_sink_tokens
+            if sliding_window_size is not None:
+                cfg.sliding_window_size = sliding_window_size
+            if num_last_tokens is not None:
+                cfg.num_last_tokens = num_last_tokens
+        self.pattern = cfg.pattern()
+        self.layer_idx = layer_idx or 0
+        if use_triangle is None:
+            use_triangle = trianglemix_config is not None and trianglemix_config.uses_triangle(self.layer_idx)
+        self.use_triangle = bool(use_triangle)
+        # requests of at most this many tokens keep plain causal attention: the reference applies
+        # its masks only above the gate (trianglemix_attention.py:330-332)
+        self.tri_min_len = int(short_sequence_gate) + 1
+
+    def forward(self, layer, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, kv_cache: torch.Tensor,
+                attn_metadata: Optional[TriangleMixAttentionMetadata], output: Optional[torch.Tensor] = None,
+                output_scale: Optional[torch.Tensor] = None, output_block_scale: Optional[torch.Tensor] = None
+                ) -> torch.Tensor:
+        """query ``[T, H, D]``, key/value ``[T, Hkv, D]``, kv_cache ``[2, num_blocks, block_size, Hkv, D]``;
+        the result is written in place into ``output[:num_actual_tokens]`` (rocm_attn.py:275-426)."""
+        assert output is not None, "Output tensor must be provided."
+        if output_scale is not None or output_block_scale is not None:
+            raise NotImplementedError("fused output quantization is not supported for TriangleMixAttentionImpl")
+        if attn_metadata is None:  # profiling run
+            return output
+        m = attn_metadata
+        n_tok = m.num_actual_tokens
+        key_cache, value_cache = kv_cache.unbind(0)
+        if self.kv_sharing_target_layer_name is None and key is not None and value is not None:
+            ops.reshape_and_cache(key[:n_tok], value[:n_tok], key_cache, value_cache, m.slot_mapping[:n_tok])
+        q = query.view(-1, self.num_heads, self.head_size)[:n_tok]
+        out = output.view(-1, self.num_heads, self.head_size)[:n_tok]
+        mode = "triangle" if self.use_triangle else "causal"
+        pattern = self.pattern if self.use_triangle else (0, 0, 0)
+        tri_min_len = self.tri_min_len if self.use_triangle else 0
+        idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len)
+        ws = m.workspace(idx, self.num_heads, self.head_size, q.device)
+        ops.attention(q, key_cache, value_cache, out, idx, m.query_start_loc, m.seq_lens, self.scale,
+                      block_table=m.block_table, workspace=ws)
+        return output
+

@@ -28,6 +28,8 @@
 // products, and every lane ends with 8 consecutive output columns per store.
 #include "tmx_common.h"
 
+#include <type_traits>
+
 namespace tmx {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -126,6 +128,12 @@ __device__ __forceinline__ float load_bias(const void* bias, int dtype, int64_t 
   return dtype == TMX_BF16 ? Bf16Traits::to_float(b) : F16Traits::to_float(b);
 }
 
+// The value, hidden from the optimiser: what is computed from it is computed where it is written.
+__device__ __forceinline__ int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
@@ -194,28 +202,35 @@ __device__ __forceinline__ void glds16_s(const void* sbase, int voff, unsigned l
 // need no special cases (scores are finite; a fully masked row still ends with sum 0 -> NaN).
 constexpr float kMinusBig = -1.0e30f;
 
-// Key tiles consumed per synchronisation step (wait + barrier + refill) of the attention kernel.
-constexpr int kTilesPerStep = 2;
+// Workgroup shape of the attention kernel: 4 (head, 32-row) slots x 2 sixteen-row blocks = 8 waves
+// of 16 query rows each; all of them share the K/V tiles of one K/V head.
+constexpr int kWaves = 2 * kWavesPerWG;
+// Key tiles per softmax step: a step takes every remaining tile of the item when there are at most
+// kGroupMax of them (the sink + window items of the triangle pattern), otherwise 2.
+constexpr int kGroupMax = 2;
 
 // Persistent, software-pipelined kernel.  Every workgroup walks work items
 // item0, item0 + step, ... for ONE K/V head chunk and streams their inputs
-// through a ring of NS LDS entries of equal size: per item first RB "Q entries"
+// through a ring of NS LDS entries of equal size: per item first 2 "Q entries"
 // (16 rows per wave each), then one entry per key tile ([K | V], 32 keys).
-// Entries are fetched by LDS-DMA NS - 1 entries ahead of their use, across
+// Entries are fetched by LDS-DMA up to NS entries ahead of their use, across
 // item boundaries, so the loads of the next item are in flight while the
 // current one is computed and stored.
-template <typename TR, int D, int NS, int RB, bool PAGED, bool HAS_BIAS>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
+template <typename TR, int D, int NS, bool PAGED, bool HAS_BIAS>
+__global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p) {
   constexpr int KS = D / 32;            // k-steps of S^T = K Q^T
   constexpr int DB = D / 16;            // 16-column output blocks
   constexpr int ROWB = D * 2;           // bytes per Q/K/V row in LDS
   constexpr int CPR = D / 8;            // 16-byte chunks per row
-  constexpr int ENTRY = 64 * ROWB;      // ring entry: K tile + V tile, or 4 waves x 16 Q rows
+  constexpr int ENTRY = 64 * ROWB;      // ring entry: K tile + V tile, or 4 slots x 16 Q rows
   constexpr int HALF = ENTRY / 2;
+  constexpr int REGION = ENTRY / 4;     // one slot's 16 Q rows
   constexpr int RPP = 1024 / ROWB;      // rows per 1-KiB LDS-DMA piece (one wave instruction)
-  constexpr int DPT = ENTRY / 1024 / 4; // LDS-DMA instructions per wave and entry
-  constexpr int U = DPT / 2;            // ... per tensor of a K/V entry
-  static_assert((NS & (NS - 1)) == 0, "ring size must be a power of two");
+  constexpr int PE = ENTRY / 1024;      // pieces per entry
+  constexpr int PW = PE / kWaves;       // ... fetched by each wave
+  constexpr int PT = PE / 2;            // ... per tensor of a K/V entry
+  constexpr int PR = PE / 4;            // ... per Q region
+  static_assert(PW >= 1 && NS >= kGroupMax + 2, "ring too small");
   using frag = typename TR::frag;
 
   __shared__ __attribute__((aligned(16))) char lds[NS * ENTRY];
@@ -227,36 +242,42 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   const unsigned lds_base = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds));
 
-  const int hg = wave % p.Gw;           // this wave's head inside the workgroup's head group
-  const int rbw = (wave / p.Gw) * RB;   // its first 16-row block inside the q-block
-  // fixed for the workgroup: K/V head and query head (the grid is a multiple of Y, or has <= Y workgroups)
+  const int sub = wave & 3, half = wave >> 2;
+  const int hg = sub % p.Gw;                  // this wave's head inside the workgroup's head group
+  const int rb16 = (sub / p.Gw) * 2 + half;   // its 16-row block inside the q-block
+  // fixed for the workgroup: K/V head and query heads (the grid is a multiple of Y, or has <= Y workgroups)
   const int kvc = blockIdx.x % p.Y;
   const int chunks = p.G / p.Gw;
   const int kvh = kvc / chunks;
-  const int head = kvh * p.G + (kvc - kvh * chunks) * p.Gw + hg;
+  const int head0 = kvh * p.G + (kvc - kvh * chunks) * p.Gw;
+  const int head = head0 + hg;
   const int item0 = blockIdx.x / p.Y;
   const int item_step = (int)gridDim.x / p.Y;  // 0: every workgroup has a single item
 
-  const char* const qbytes = reinterpret_cast<const char*>(p.q) + 2ll * head * p.q_stride_h;
-  const char* const kbytes = reinterpret_cast<const char*>(p.k) + 2ll * kvh * p.kv_stride_h;
-  const char* const vbytes = reinterpret_cast<const char*>(p.v) + 2ll * kvh * p.kv_stride_h;
   const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = 2 * p.kv_stride_t;
 
-  // ---- per-lane constants of the LDS-DMA issue: byte offsets relative to a wave-uniform base ----
+  // ---- LDS-DMA issue: wave-uniform bases + per-lane constant byte offsets ----
+  // Every wave fetches pieces wave * PW .. + PW - 1 of every entry.  In a Q entry they belong to
+  // slot `rq` (not the wave's own), in a K/V entry to one 16-key half of K or of V.
   const int piece_row = lane / CPR;  // row of this lane inside a 1-KiB piece
   const int piece_cc = lane % CPR;   // its 16-byte chunk
-  int q_voff[DPT];                   // Q entry: rows x * RPP + piece_row of this wave's 16-row block
+  const int pi0 = wave * PW;
+  const int rq = pi0 / PR;
+  const char* const q_iss = reinterpret_cast<const char*>(p.q) + 2ll * (head0 + rq % p.Gw) * p.q_stride_h;
+  const int q_iss_row0 = 32 * (rq / p.Gw);
+  const int pir0 = pi0 % PR;
+  const bool iss_v = pi0 >= PT;
+  const int pit0 = pi0 % PT;
+  const bool iss_second = pit0 * RPP >= 16;  // keys 16..31 of the tile
+  const char* const kv_iss =
+      reinterpret_cast<const char*>(iss_v ? p.v : p.k) + 2ll * kvh * p.kv_stride_h;
+  int q_voff[PW], kv_voff[PW];
 #pragma unroll
-  for (int x = 0; x < DPT; ++x) {
-    const int r16 = x * RPP + piece_row;
+  for (int x = 0; x < PW; ++x) {
+    const int r16 = (pir0 + x) * RPP + piece_row;
     q_voff[x] = r16 * q_row_bytes + 16 * (piece_cc ^ k_chunk_swizzle<D>(r16));
-  }
-  int k_voff[U], v_voff[U];          // K/V entry: rows (wave * U + x) * RPP + piece_row of the 32-key tile
-#pragma unroll
-  for (int x = 0; x < U; ++x) {
-    const int row = (wave * U + x) * RPP + piece_row;
-    k_voff[x] = row * kv_row_bytes + 16 * (piece_cc ^ k_chunk_swizzle<D>(row));
-    v_voff[x] = row * kv_row_bytes + 16 * (piece_cc ^ v_chunk_swizzle<D>(row));
+    const int row = (pit0 + x) * RPP + piece_row;
+    kv_voff[x] = row * kv_row_bytes + 16 * (piece_cc ^ (iss_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row)));
   }
 
   // ------------------------------------------------------------------ issue side (all scalar)
@@ -277,7 +298,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   ib_valid = fetch_item(1, ib0, ib1);
   int ik = 0;   // ordinal of the issue item among this workgroup's items
   int ie = 0;   // its entries already issued
-  int gi = 0;   // entries issued so far (ring position)
+  int gi = 0;   // entries issued so far
+  int gi_slot = 0;  // gi mod NS
   // descriptor of the next K/V entry to issue, fetched one step ahead
   int d_tile = 0;
   long long d_off0 = 0, d_off1 = 0;  // byte offsets of the pages holding the tile's keys 0..15 / 16..31
@@ -285,8 +307,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 
   auto prefetch_desc = [&]() {
     // item fields: a0 = (qb, col_start, ntiles, slot), a1 = (b, q_tok0, pos0, n)
-    if (!i_valid || ie < RB || ie >= RB + ia0.z) return;
-    const int pos = ia0.y + (ie - RB);
+    if (!i_valid || ie < 2 || ie >= 2 + ia0.z) return;
+    const int pos = ia0.y + (ie - 2);
     d_tile = sload(p.col_idx + pos);
     if constexpr (PAGED) {
       if (p.tile_pages != nullptr) {
@@ -302,67 +324,63 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   };
 
   auto issue_one = [&]() {
-    const unsigned dst = lds_base + ((unsigned)gi & (NS - 1)) * ENTRY;
+    const unsigned dst = lds_base + (unsigned)gi_slot * ENTRY + pi0 * 1024;
     const int n = ia1.w;
-    if (ie < RB) {
-      // Q entry: this wave's 16 rows of row block rbw + ie
+    if (ie < 2) {
+      // Q entry ie: rows 16 * ie .. + 15 of every slot's 32 rows
       const int rows_valid = imin(p.block_m, n - ia1.z);
-      const int r0 = 16 * (rbw + ie);
-      const unsigned qdst = dst + wave * (ENTRY / 4);
+      const int r0 = q_iss_row0 + 16 * ie;
       if (r0 + 16 <= rows_valid) {
-        const char* sb = qbytes + (long long)(ia1.y + r0) * q_row_bytes;
+        const char* sb = q_iss + (long long)(ia1.y + r0) * q_row_bytes;
 #pragma unroll
-        for (int x = 0; x < DPT; ++x) glds16_s(sb, q_voff[x], qdst + x * 1024);
+        for (int x = 0; x < PW; ++x) glds16_s(sb, q_voff[x], dst + x * 1024);
       } else {
         // ragged last block: rows past the end of the request are never stored; read a valid row instead
+        const int l2 = opaque(lane);  // recomputed here: nothing of the rare path stays live in the main loop
 #pragma unroll
-        for (int x = 0; x < DPT; ++x) {
-          const int r16 = x * RPP + piece_row;
+        for (int x = 0; x < PW; ++x) {
+          const int r16 = (pir0 + x) * RPP + l2 / CPR;
           const int r = imax(0, imin(r0 + r16, rows_valid - 1));
-          glds16(qbytes + (long long)(ia1.y + r) * q_row_bytes + 16 * (piece_cc ^ k_chunk_swizzle<D>(r16)),
-                 qdst + x * 1024);
+          glds16(q_iss + (long long)(ia1.y + r) * q_row_bytes + 16 * ((l2 % CPR) ^ k_chunk_swizzle<D>(r16)),
+                 dst + x * 1024);
         }
       }
     } else {
       const int j0 = d_tile * kBlockN;
       if (j0 + kBlockN <= n) {
         // whole tile inside the sequence: one wave-uniform base per 16-key half
-        long long b0, b1;
+        long long bb;
         if constexpr (PAGED) {
-          const long long in_page = (long long)(j0 & (p.page_size - 1)) * kv_row_bytes;
-          b0 = d_off0 + in_page;
-          b1 = (p.page_size > 16) ? b0 : d_off1 - 16ll * kv_row_bytes;
+          const long long b0 = d_off0 + (long long)(j0 & (p.page_size - 1)) * kv_row_bytes;
+          bb = (iss_second && p.page_size == 16) ? d_off1 - 16ll * kv_row_bytes : b0;
         } else {
-          b0 = b1 = (i_krow0 + j0) * kv_row_bytes;
+          bb = (i_krow0 + j0) * kv_row_bytes;
         }
 #pragma unroll
-        for (int x = 0; x < U; ++x) {
-          const int piece = wave * U + x;
-          const long long bb = (piece * RPP >= 16) ? b1 : b0;
-          glds16_s(kbytes + bb, k_voff[x], dst + piece * 1024);
-          glds16_s(vbytes + bb, v_voff[x], dst + HALF + piece * 1024);
-        }
+        for (int x = 0; x < PW; ++x) glds16_s(kv_iss + bb, kv_voff[x], dst + x * 1024);
       } else {
         // last, partial tile: keys past the end are masked later; clamp their source to the last key
+        const int l2 = opaque(lane);
 #pragma unroll
-        for (int x = 0; x < U; ++x) {
-          const int piece = wave * U + x;
-          const int row = piece * RPP + piece_row;
+        for (int x = 0; x < PW; ++x) {
+          const int row = (pit0 + x) * RPP + l2 / CPR;
           const int j = imin(j0 + row, n - 1);
           long long off;
           if constexpr (PAGED) {
-            off = (((j - j0) >= 16 && p.page_size == 16) ? d_off1 : d_off0) + (long long)(j & (p.page_size - 1)) * kv_row_bytes;
+            off = (((j - j0) >= 16 && p.page_size == 16) ? d_off1 : d_off0) +
+                  (long long)(j & (p.page_size - 1)) * kv_row_bytes;
           } else {
             off = (i_krow0 + j) * kv_row_bytes;
           }
-          glds16(kbytes + off + 16 * (piece_cc ^ k_chunk_swizzle<D>(row)), dst + piece * 1024);
-          glds16(vbytes + off + 16 * (piece_cc ^ v_chunk_swizzle<D>(row)), dst + HALF + piece * 1024);
+          const int swz = iss_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row);
+          glds16(kv_iss + off + 16 * ((l2 % CPR) ^ swz), dst + x * 1024);
         }
       }
     }
     ++ie;
     ++gi;
-    if (ie == RB + ia0.z) {
+    gi_slot = (gi_slot + 1 == NS) ? 0 : gi_slot + 1;
+    if (ie == 2 + ia0.z) {
       ia0 = ib0;
       ia1 = ib1;
       i_valid = ib_valid;
@@ -384,17 +402,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     if (i_valid) issue_one();
 
   // ------------------------------------------------------------------ compute side
-  // per-lane LDS read offsets inside an entry
-  int k_off[KS];  // K / Q row qi, chunk 4 * ks + g (swizzled)
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) k_off[ks] = qi * ROWB + 16 * ((4 * ks + g) ^ k_chunk_swizzle<D>(qi));
+  // per-lane LDS read offsets inside an entry: K / Q row qi, chunk 4 * ks + g is at k_base ^ (64 * ks)
+  const int k_base = qi * ROWB + 16 * (g ^ k_chunk_swizzle<D>(qi));
   // V transposed read: lane 4 * q' + pp of each 16-lane group addresses key row 4 * g + q' (+16 for the
-  // second half of the tile), columns 16 * db + 4 * pp .. +3
+  // second half of the tile), columns 16 * db + 4 * pp .. +3, at v_base ^ (32 * db)
   const int v_row = 4 * g + ((lane & 15) >> 2);
-  const int v_x = v_chunk_swizzle<D>(v_row) >> 1;  // XOR on the 32-byte group index == the output block db
-  int v_off[DB];
-#pragma unroll
-  for (int db = 0; db < DB; ++db) v_off[db] = HALF + v_row * ROWB + 8 * (lane & 3) + 32 * (db ^ v_x);
+  const int v_base = HALF + v_row * ROWB + 8 * (lane & 3) + 32 * (v_chunk_swizzle<D>(v_row) >> 1);
   const int koff_lane = 4 * g;  // this lane's first key inside a 16-key half tile
 
   i32x4 ca0, ca1, cb0, cb1;
@@ -402,7 +415,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   int cb_valid = fetch_item(1, cb0, cb1);
   int ck = 0;
   int gs = 0;          // entries consumed so far
-  int store_mark = 0;  // entries with ring position < store_mark were issued before the last stores
+  int gs_slot = 0;     // gs mod NS
+  int store_mark = 0;  // entries below store_mark were issued before the last stores
   int store_ops = 0;   // vector-memory instructions of those stores (this wave)
 
 #ifdef TMX_STAMPS
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   // slots the previous step freed (entries below gs are consumed once every wave is past the barrier).
   auto step_sync = [&](int cnt) {
     TMX_STAMP(ts0);
-    wait_vmcnt_levels<DPT>(DPT * (gi - gs - cnt) + (gs + cnt - 1 < store_mark ? store_ops : 0));
+    wait_vmcnt_levels<PW>(PW * (gi - gs - cnt) + (gs + cnt - 1 < store_mark ? store_ops : 0));
     TMX_STAMP(ts1);
 #ifndef TMX_ABLATE_BARRIER
     __builtin_amdgcn_s_barrier();
@@ -429,6 +443,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     TMX_SEG(1, ts1, ts2);
     TMX_SEG(2, ts2, ts3);
   };
+  auto slot_after = [&](int s, int k) { return s + k >= NS ? s + k - NS : s + k; };
+
+  const float mult = HAS_BIAS ? 1.0f : p.scale_log2;  // factor between the accumulated scores and the exponent
 
   while (c_valid) {
     const int col_start = ca0.y, ntiles = ca0.z, slot = ca0.w;
@@ -436,213 +453,234 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const int rows_valid = imin(p.block_m, n - pos0);
     const int mode = effective_mode(p.mode, n, p.tri_min_len);
 
-    // ---- Q fragments of this wave's RB row blocks (B operand of S^T) ----
-    frag qf[RB][KS];
-    step_sync(RB);
+    // tile numbers of the first group (clamped reads stay inside the item's list)
+    int nt[kGroupMax];
 #pragma unroll
-    for (int e = 0; e < RB; ++e) {
-      const char* qs = lds + ((unsigned)(gs + e) & (NS - 1)) * ENTRY + wave * (ENTRY / 4);
+    for (int u = 0; u < kGroupMax; ++u) nt[u] = ntiles > 0 ? sload(p.col_idx + col_start + imin(u, ntiles - 1)) : 0;
+
+    // ---- Q fragments of this wave's 16 rows (B operand of S^T) ----
+    frag qf[KS];
+    step_sync(2);
+    {
+      const char* qs = lds + slot_after(gs_slot, half) * ENTRY + sub * REGION;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        qf[e][ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(qs + k_off[ks]));
+        qf[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(qs + (k_base ^ (64 * ks))));
     }
-    gs += RB;
+    gs += 2;
+    gs_slot = slot_after(gs_slot, 2);
 
-    // ---- wave-uniform row range of the wave's 16 * RB rows, per-lane form of the predicate ----
+    // ---- wave-uniform row range of the wave's 16 rows, per-lane form of the predicate ----
     // key j is attended by this lane's row iff j <= key_hi and not (hole_lo < j < hole_lo + 1 + hole_width)
-    const int w_row0 = 16 * rbw;
-    const int w_row1 = imin(w_row0 + 16 * RB, rows_valid);
+    const int w_row0 = 16 * rb16;
+    const int w_row1 = imin(w_row0 + 16, rows_valid);
     const bool w_has_rows = w_row0 < rows_valid;
     const int w_imin = pos0 + w_row0, w_imax = pos0 + w_row1 - 1;
     const bool w_all_last = (n - w_imin) < p.last;
     const int hole_lo = p.si < -1 ? -1 : p.si;
-    int key_hi[RB];
-    unsigned hole_width[RB];
-    bool row_valid[RB];
-#pragma unroll
-    for (int e = 0; e < RB; ++e) {
-      const int my_row = w_row0 + 16 * e + qi;
-      row_valid[e] = my_row < rows_valid;
-      const int pos_i = pos0 + my_row;
-      key_hi[e] = -1;
-      hole_width[e] = 0;
-      if (row_valid[e]) {
-        key_hi[e] = (mode == TMX_MODE_NONE) ? n - 1 : imin(pos_i, n - 1);
-        if (mode == TMX_MODE_TRIANGLE && !((n - pos_i) < p.last)) {
-          // keys si < j < pos_i - sl are the excluded middle section
-          const long long w = (long long)pos_i - p.sl - (long long)hole_lo - 1;
-          hole_width[e] = w > 0 ? (unsigned)w : 0u;
-        }
+    const int my_row = w_row0 + qi;
+    const bool row_valid = my_row < rows_valid;
+    const int pos_i = pos0 + my_row;
+    int key_hi = -1;
+    unsigned hole_width = 0;
+    if (row_valid) {
+      key_hi = (mode == TMX_MODE_NONE) ? n - 1 : imin(pos_i, n - 1);
+      if (mode == TMX_MODE_TRIANGLE && !((n - pos_i) < p.last)) {
+        // keys si < j < pos_i - sl are the excluded middle section
+        const long long w = (long long)pos_i - p.sl - (long long)hole_lo - 1;
+        hole_width = w > 0 ? (unsigned)w : 0u;
       }
     }
 
-    f32x4 acc[RB][DB];
-    float m_run[RB], l_run[RB];
+    f32x4 acc[DB];
 #pragma unroll
-    for (int e = 0; e < RB; ++e) {
-      m_run[e] = kMinusBig;
-      l_run[e] = 0.f;
-#pragma unroll
-      for (int db = 0; db < DB; ++db) acc[e][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int db = 0; db < DB; ++db) acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = kMinusBig, l_run = 0.f;
 
-    int tile = ntiles > 0 ? sload(p.col_idx + col_start) : 0;
-    int in_step = 0;  // entries of the current step not yet consumed
-#pragma unroll 1
-    for (int t = 0; t < ntiles; ++t) {
-      if (in_step == 0) {
-        in_step = imin(kTilesPerStep, ntiles - t);
-        step_sync(in_step);
-      }
-      --in_step;
-      const char* es = lds + ((unsigned)gs & (NS - 1)) * ENTRY;
-      ++gs;
-      const int j0 = tile * kBlockN, j1 = j0 + kBlockN - 1;
-      if (t + 1 < ntiles) tile = sload(p.col_idx + col_start + t + 1);  // for the next iteration
-
-      // `full`: every (row, key) pair of the wave's rows and this tile is attended (wave-uniform),
-      // so the per-element predicate is skipped.  Everything else goes through the predicate.
-      bool full;
-      if (mode == TMX_MODE_NONE) {
-        full = j1 < n;
-      } else {
-        full = j1 <= w_imin;
-        if (mode == TMX_MODE_TRIANGLE && !w_all_last) full = full && (j1 <= p.si || j0 >= w_imax - p.sl);
-      }
-#ifdef TMX_ABLATE_COMPUTE
-      if (p.scale_log2 != 12345.f) continue;
-#endif
-      if (!w_has_rows) continue;
+    // One softmax step over CNT key tiles (ring entries gs .. gs + CNT - 1).
+    auto process = [&](auto cnt_c, const int (&tl)[kGroupMax], bool first) {
+      constexpr int CNT = decltype(cnt_c)::value;
       TMX_STAMP(ts0);
+      const char* es[CNT];
+#pragma unroll
+      for (int u = 0; u < CNT; ++u) es[u] = lds + slot_after(gs_slot, u) * ENTRY;
 
-      // S^T = K Q^T: K fragments are read once for all row blocks
-      f32x4 s[RB][2];
+      // S^T = K Q^T for every tile of the group: 2 * CNT independent accumulator chains
+      f32x4 s[CNT][2];
 #pragma unroll
-      for (int e = 0; e < RB; ++e) s[e][0] = s[e][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < CNT; ++u) s[u][0] = s[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const frag kf = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(es + kb * 16 * ROWB + k_off[ks]));
+        for (int u = 0; u < CNT; ++u)
 #pragma unroll
-          for (int e = 0; e < RB; ++e) s[e][kb] = TR::mfma(kf, qf[e][ks], s[e][kb]);
-        }
+          for (int kb = 0; kb < 2; ++kb) {
+            const frag kf = __builtin_bit_cast(
+                frag, *reinterpret_cast<const uint4*>(es[u] + kb * 16 * ROWB + (k_base ^ (64 * ks))));
+            s[u][kb] = TR::mfma(kf, qf[ks], s[u][kb]);
+          }
 
-      // online softmax per row block; P stays in registers as the B operand of the second product
-      frag pf[RB];
+      float tmax = -__builtin_inff();
 #pragma unroll
-      for (int e = 0; e < RB; ++e) {
-        float x[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) x[c] = s[e][c >> 2][c & 3] * p.scale_log2;
+      for (int u = 0; u < CNT; ++u) {
+        const int j0 = tl[u] * kBlockN, j1 = j0 + kBlockN - 1;
         if constexpr (HAS_BIAS) {
-          const int pos_i = pos0 + w_row0 + 16 * e + qi;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
             const int j = j0 + 16 * (c >> 2) + koff_lane + (c & 3);
-            if (row_valid[e] && j < p.bias_cols && pos_i < p.bias_rows && j <= key_hi[e])
-              x[c] += kLog2e * load_bias(p.bias, p.bias_dtype, (long long)pos_i * p.bias_stride + j);
+            float b = 0.f;
+            if (row_valid && j < p.bias_cols && pos_i < p.bias_rows && j <= key_hi)
+              b = kLog2e * load_bias(p.bias, p.bias_dtype, (long long)pos_i * p.bias_stride + j);
+            s[u][c >> 2][c & 3] = s[u][c >> 2][c & 3] * p.scale_log2 + b;
           }
+        }
+        // `full`: every (row, key) pair of the wave's rows and this tile is attended (wave-uniform),
+        // so the per-element predicate is skipped.  Everything else goes through the predicate.
+        bool full;
+        if (mode == TMX_MODE_NONE) {
+          full = j1 < n;
+        } else {
+          full = j1 <= w_imin;
+          if (mode == TMX_MODE_TRIANGLE && !w_all_last) full = full && (j1 <= p.si || j0 >= w_imax - p.sl);
         }
         if (!full) {
           const int jl = j0 + koff_lane;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
             const int j = jl + 16 * (c >> 2) + (c & 3);
-            const bool in_hole = (unsigned)(j - hole_lo - 1) < hole_width[e];
-            x[c] = (j <= key_hi[e] && !in_hole) ? x[c] : -__builtin_inff();
+            const bool in_hole = (unsigned)(j - hole_lo - 1) < hole_width;
+            s[u][c >> 2][c & 3] = (j <= key_hi && !in_hole) ? s[u][c >> 2][c & 3] : -__builtin_inff();
           }
         }
-        float tmax = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run[e], tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[e] - m_new);
-        m_run[e] = m_new;
-        float psum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tmax = fmaxf(tmax, s[u][c >> 2][c & 3]);
+      }
+      // maximum over the 4 lanes that share a row (lanes l, l ^ 16, l ^ 32, l ^ 48)
+      {
+        const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+        const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+      }
+      const float m_new = fmaxf(m_run, tmax * mult);  // mult > 0
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+      frag pf[CNT];
+#pragma unroll
+      for (int u = 0; u < CNT; ++u) {
         s16x8 pk;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const float pe = __builtin_amdgcn_exp2f(x[c] - m_new);
+          const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][c >> 2][c & 3], mult, -m_new));
           psum += pe;
           pk[c] = TR::cvt(pe);
         }
-        l_run[e] = l_run[e] * alpha + psum;
-        pf[e] = __builtin_bit_cast(frag, pk);
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // wave-uniform: some row's maximum moved
+        pf[u] = __builtin_bit_cast(frag, pk);
+      }
+      l_run = l_run * alpha + psum;
+      if (!first && __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // wave-uniform: some row's maximum moved
 #pragma unroll
-          for (int db = 0; db < DB; ++db) acc[e][db] *= alpha;
-        }
+        for (int db = 0; db < DB; ++db) acc[db] *= alpha;
       }
 
-      // O^T += V^T P^T (V fragments are read once, transposed by the LDS read)
+      // O^T += V^T P^T (V fragments transposed by the LDS read)
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(es + v_off[db]));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(es + 16 * ROWB + v_off[db]));
-        const frag vf = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int e = 0; e < RB; ++e) acc[e][db] = TR::mfma(vf, pf[e], acc[e][db]);
-      }
+        for (int u = 0; u < CNT; ++u) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(es[u] + (v_base ^ (32 * db))));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(es[u] + 16 * ROWB + (v_base ^ (32 * db))));
+          const frag vf = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          acc[db] = TR::mfma(vf, pf[u], acc[db]);
+        }
       TMX_STAMP(ts1);
       TMX_SEG(3, ts0, ts1);
+    };
+
+#pragma unroll 1
+    for (int t = 0; t < ntiles;) {
+      const int cnt = (ntiles - t <= kGroupMax) ? ntiles - t : 2;
+      step_sync(cnt);
+      int tl[kGroupMax];
+#pragma unroll
+      for (int u = 0; u < kGroupMax; ++u) tl[u] = nt[u];
+      const int t_next = t + cnt;
+      if (t_next < ntiles) {
+#pragma unroll
+        for (int u = 0; u < kGroupMax; ++u) nt[u] = sload(p.col_idx + col_start + imin(t_next + u, ntiles - 1));
+      }
+#ifdef TMX_ABLATE_COMPUTE
+      const bool compute = w_has_rows && p.scale_log2 == 12345.f;
+#else
+      const bool compute = w_has_rows;
+#endif
+      if (compute) {
+        if (cnt == 3) process(std::integral_constant<int, 3>{}, tl, t == 0);
+        else if (cnt == 2) process(std::integral_constant<int, 2>{}, tl, t == 0);
+        else process(std::integral_constant<int, 1>{}, tl, t == 0);
+      }
+      gs += cnt;
+      gs_slot = slot_after(gs_slot, cnt);
+      t = t_next;
     }
     TMX_STAMP(ts0);
 
     // ---- epilogue: lane (qi, g) holds columns 16 * db + 4 * g .. +3 of its row for every db ----
     int stores = 0;
-#pragma unroll
-    for (int e = 0; e < RB; ++e) {
-      float l_tot = l_run[e] + __shfl_xor(l_run[e], 16, 64);
-      l_tot += __shfl_xor(l_tot, 32, 64);
-      const int my_row = w_row0 + 16 * e + qi;
-      if (w_row0 + 16 * e >= rows_valid) continue;  // wave-uniform: the row block is past the request
+    if (w_has_rows) {
+      float l_tot;
+      {
+        const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_tot = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+        const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+        l_tot = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+      }
       if (slot >= 0) {
         // piece of a split q-block: unnormalised fp32 accumulator + (max, sum) for the combine pass
         const long long prow = ((long long)slot * p.H + head) * p.block_m + my_row;
         float* po = p.partial_o + prow * D + 4 * g;
-        if (row_valid[e]) {
+        if (row_valid) {
 #pragma unroll
           for (int db = 0; db < DB; ++db)
-            *reinterpret_cast<float4*>(po + 16 * db) =
-                make_float4(acc[e][db][0], acc[e][db][1], acc[e][db][2], acc[e][db][3]);
-          if (g == 0) *reinterpret_cast<float2*>(p.partial_ml + prow * 2) = make_float2(m_run[e], l_tot);
+            *reinterpret_cast<float4*>(po + 16 * db) = make_float4(acc[db][0], acc[db][1], acc[db][2], acc[db][3]);
+          if (g == 0) *reinterpret_cast<float2*>(p.partial_ml + prow * 2) = make_float2(m_run, l_tot);
         }
-        stores += DB;  // the (max, sum) store may be skipped by lanes; counting fewer only waits longer
-        continue;
-      }
-      const float inv = 1.0f / l_tot;  // a fully masked row gives 0 * inf = NaN, as softmax over all -inf does
-      const long long orow = (long long)(q_tok0 + my_row) * p.out_stride_t + (long long)head * p.out_stride_h;
-      if (p.out_dtype == TMX_F32) {
-        float* po = reinterpret_cast<float*>(p.out) + orow + 4 * g;
-        if (row_valid[e]) {
-#pragma unroll
-          for (int db = 0; db < DB; ++db)
-            *reinterpret_cast<float4*>(po + 16 * db) = make_float4(acc[e][db][0] * inv, acc[e][db][1] * inv,
-                                                                  acc[e][db][2] * inv, acc[e][db][3] * inv);
-        }
-        stores += DB;
+        stores = DB;  // the (max, sum) store may be skipped by lanes; counting fewer only waits longer
       } else {
-        // 16-bit output: lanes l and l ^ 16 exchange one 8-byte piece per pair of output blocks so
-        // that every lane stores 16 contiguous bytes (8 columns)
-        uint16_t* po = reinterpret_cast<uint16_t*>(p.out) + orow + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
+        const float inv = 1.0f / l_tot;  // a fully masked row gives 0 * inf = NaN, as softmax over all -inf does
+        const long long orow = (long long)(q_tok0 + my_row) * p.out_stride_t + (long long)head * p.out_stride_h;
+        if (p.out_dtype == TMX_F32) {
+          float* po = reinterpret_cast<float*>(p.out) + orow + 4 * g;
+          if (row_valid) {
 #pragma unroll
-        for (int c = 0; c < DB / 2; ++c) {
-          s16x4 a, bq;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            a[r] = TR::cvt(acc[e][2 * c][r] * inv);
-            bq[r] = TR::cvt(acc[e][2 * c + 1][r] * inv);
+            for (int db = 0; db < DB; ++db)
+              *reinterpret_cast<float4*>(po + 16 * db) =
+                  make_float4(acc[db][0] * inv, acc[db][1] * inv, acc[db][2] * inv, acc[db][3] * inv);
           }
-          const uint2 au = __builtin_bit_cast(uint2, a), bu = __builtin_bit_cast(uint2, bq);
-          const auto r0 = __builtin_amdgcn_permlane16_swap(au.x, bu.x, false, false);
-          const auto r1 = __builtin_amdgcn_permlane16_swap(au.y, bu.y, false, false);
-          // even 16-lane rows: [own block 2c | partner's block 2c]; odd rows: [partner's block 2c+1 | own]
-          if (row_valid[e]) *reinterpret_cast<uint4*>(po + 32 * c) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          stores = DB;
+        } else {
+          // 16-bit output: lanes l and l ^ 16 exchange one 8-byte piece per pair of output blocks so
+          // that every lane stores 16 contiguous bytes (8 columns)
+          uint16_t* po = reinterpret_cast<uint16_t*>(p.out) + orow + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
+#pragma unroll
+          for (int c = 0; c < DB / 2; ++c) {
+            s16x4 a, bq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              a[r] = TR::cvt(acc[2 * c][r] * inv);
+              bq[r] = TR::cvt(acc[2 * c + 1][r] * inv);
+            }
+            const uint2 au = __builtin_bit_cast(uint2, a), bu = __builtin_bit_cast(uint2, bq);
+            const auto r0 = __builtin_amdgcn_permlane16_swap(au.x, bu.x, false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(au.y, bu.y, false, false);
+            // even 16-lane rows: [own block 2c | partner's block 2c]; odd rows: [partner's block 2c+1 | own]
+            if (row_valid) *reinterpret_cast<uint4*>(po + 32 * c) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          }
+          stores = DB / 2;
         }
-        stores += DB / 2;
       }
     }
     store_mark = gi;
@@ -663,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   seg[6] = ts4 - t_begin;
   seg[7] = (unsigned long long)gs;
   if (p.stamps != nullptr && lane == 0) {
-    unsigned long long* dst = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+    unsigned long long* dst = p.stamps + ((size_t)blockIdx.x * kWaves + wave) * 8;
     for (int x = 0; x < 8; ++x) dst[x] = seg[x];
   }
 #endif
@@ -729,7 +767,7 @@ __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p
   }
 }
 
-constexpr int kRingSlots = 4;  // LDS ring entries; NS - 1 are in flight
+constexpr int kRingSlots = 5;  // LDS ring entries of the attention kernel
 
 // Persistent grid: as many workgroups as stay resident (LDS and registers allow a fixed number per
 // CU), rounded down to a multiple of the units per item so that a workgroup keeps one K/V head.
@@ -738,7 +776,7 @@ static int persistent_grid(K kernel, const AttnParams& p, unsigned* grid_out) {
   int dev = 0, cus = 0, per_cu = 0;
   TMX_CHECK_HIP(hipGetDevice(&dev));
   TMX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  TMX_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
+  TMX_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * kWaves, 0));
   if (per_cu < 1) per_cu = 1;
   long long w = (long long)cus * per_cu;
   if (w > p.units_total) w = p.units_total;
@@ -749,7 +787,7 @@ static int persistent_grid(K kernel, const AttnParams& p, unsigned* grid_out) {
 
 template <typename TR, int D, bool PAGED, bool HAS_BIAS>
 static int launch_attn(const AttnParams& p, hipStream_t s) {
-  auto kernel = attn_kernel<TR, D, kRingSlots, kRowBlocksPerWave, PAGED, HAS_BIAS>;
+  auto kernel = attn_kernel<TR, D, kRingSlots, PAGED, HAS_BIAS>;
   static unsigned cached_grid_cap[16] = {0};  // per device: resident workgroups of this instantiation
   int dev = 0;
   TMX_CHECK_HIP(hipGetDevice(&dev));
@@ -757,7 +795,7 @@ static int launch_attn(const AttnParams& p, hipStream_t s) {
   int rc = persistent_grid(kernel, p, &grid);
   if (rc != TMX_OK) return rc;
   (void)cached_grid_cap;
-  kernel<<<grid, 256, 0, s>>>(p);
+  kernel<<<grid, 64 * kWaves, 0, s>>>(p);
   TMX_CHECK_HIP(hipGetLastError());
   return TMX_OK;
 }
@@ -797,6 +835,8 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
                 "tmx_attention: num_heads %d must be a positive multiple of num_kv_heads %d", a->num_heads,
                 a->num_kv_heads);
   TMX_CHECK_ARG(a->mode >= TMX_MODE_NONE && a->mode <= TMX_MODE_TRIANGLE, "tmx_attention: bad mode %d", a->mode);
+  TMX_CHECK_ARG(a->scale > 0.f && a->scale < 3.0e38f, "tmx_attention: scale %g must be positive and finite",
+                (double)a->scale);
   TMX_CHECK_ARG(a->batch >= 0 && a->total_q >= 0 && a->num_items >= 0 && a->num_partials >= 0 &&
                     a->num_split_qblocks >= 0,
                 "tmx_attention: negative size");
