@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--seq-len", type=int, default=32768)
     ap.add_argument("--oproj", action="store_true", help="also time o_proj GEMM + all-reduce (reported separately)")
     ap.add_argument("--no-baselines", action="store_true", help="skip the dense and CPU baselines")
-    ap.add_argument("--cpu-rows", type=int, default=1024, help="query rows of the CPU-baseline sample")
-    ap.add_argument("--cpu-heads", type=int, default=2, help="heads of the CPU-baseline sample")
+    ap.add_argument("--cpu-rows", type=int, default=4096, help="query rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-heads", type=int, default=8, help="heads of the CPU-baseline sample")
     return ap.parse_args()
 
 

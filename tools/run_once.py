@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Runs a few attention launches of one configuration (for rocprofv3 --pmc / --kernel-trace).
-Usage: python tools/run_once.py MODE N [ITERS] [CHUNK]   (MODE: triangle|causal|stream|window)"""
+Usage: python tools/run_once.py MODE N [ITERS] [CHUNK] [PAGED]   (MODE: triangle|causal|stream|window;
+PAGED=1: paged K/V cache with 16-token pages and a shuffled block table, as bench.py uses)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_trianglemix_amd import ops
 from vllm_trianglemix_amd._lib import TMX_ATTN_SKIP_COMBINE
 mode = sys.argv[1]; n = int(sys.argv[2]); iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+paged = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 H, Hkv, D = 32, 8, 128
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
@@ -19,10 +21,25 @@ cu_h, sl_h = np.asarray([0, n], np.int32), np.asarray([n], np.int32)
 cu, sl = torch.from_numpy(cu_h).to(dev), torch.from_numpy(sl_h).to(dev)
 pat = {"triangle": (4, 32, 64, "triangle"), "stream": (4, 32, 0, "triangle"), "window": (-1, 32, 0, "triangle"),
        "causal": (0, 0, 0, "causal")}[mode]
+bt = None
+if paged:
+    PAGE = 16
+    nblk = (n + PAGE - 1) // PAGE
+    perm = torch.randperm(nblk, generator=g).to(torch.int32)
+    kc = torch.zeros((nblk, PAGE, Hkv, D), dtype=torch.bfloat16, device=dev)
+    vc = torch.zeros_like(kc)
+    pos = torch.arange(n)
+    ops.reshape_and_cache(k, v, kc, vc, (perm.long()[pos // PAGE] * PAGE + pos % PAGE).to(dev))
+    bt = perm.view(1, -1).to(dev)
 idx = ops.build_block_index(cu, sl, cu_h, sl_h, pat[0], pat[1], pat[2], ops.attention_block_m(H, Hkv), 32,
-                            ops.MODES[pat[3]], chunk_tiles=chunk)
+                            ops.MODES[pat[3]], chunk_tiles=chunk, block_table=bt, page_size=16 if paged else 0)
 work = ops.alloc_workspace(idx, H, D, dev)
 for _ in range(iters):
-    ops.attention(q, k, v, out, idx, cu, sl, D ** -0.5, cu_seqlens_k=cu, workspace=work, flags=TMX_ATTN_SKIP_COMBINE)
+    if paged:
+        ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=work,
+                      flags=TMX_ATTN_SKIP_COMBINE)
+    else:
+        ops.attention(q, k, v, out, idx, cu, sl, D ** -0.5, cu_seqlens_k=cu, workspace=work,
+                      flags=TMX_ATTN_SKIP_COMBINE)
 torch.cuda.synchronize()
 print("done", mode, n, idx.sizes.num_items)
