@@ -173,7 +173,7 @@ typedef struct tmx_attention_args_t {
   int32_t out_dtype;    /* TMX_BF16 / TMX_F16 (== io_dtype) or TMX_F32 */
   int32_t mode;         /* TMX_MODE_* ; must equal index->mode */
   int32_t si, sl, last; /* must equal the index parameters */
-  float scale;          /* softmax scale */
+  float scale;          /* softmax scale, > 0 (the row maximum is taken before scaling) */
 
   int32_t batch, num_heads, num_kv_heads, head_dim;
   int32_t total_q;      /* rows of q / out */

@@ -316,6 +316,7 @@ def test_attention_varlen_gqa_vs_oracle(dtype):
                               resolve_pages=resolve)
             assert not np.isnan(got).any(), (ci, paged)
             err = np.abs(got - ref).max()
+            print(f"varlen case {ci} {dtype} paged={paged}/{page_size}: max abs err {err:.2e}")
             assert err <= ATOL_F32_OUT, (ci, paged, err)
 
 
@@ -328,6 +329,7 @@ def test_attention_split_and_combine_long():
     ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], [0, n], [n], scale, "triangle", 4, 32, 64)
     for chunk in (8, 64, 1000):
         got = _run_varlen(ops, q, ks, vs, [n], [n], scale, "triangle", (4, 32, 64), paged=True, chunk=chunk)
+        print(f"split/combine chunk {chunk}: max abs err {np.abs(got - ref).max():.2e}")
         assert np.abs(got - ref).max() <= ATOL_F32_OUT, chunk
     gb = _run_varlen(ops, q, ks, vs, [n], [n], scale, "triangle", (4, 32, 64), paged=True, out_dtype=torch.bfloat16)
     assert np.all(np.abs(gb - ref) <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8)
@@ -502,3 +504,67 @@ def test_backend_forward_mixed_batch():
         assert np.all(err <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8), (layer_idx, err.max())
     # both layers asked for different modes: two indices were built and cached on the step's metadata
     assert len(md._indices) == 2
+
+
+def test_torch_library_binding_equals_ctypes_path():
+    """torch.ops._trianglemix_C.* (TORCH_LIBRARY registration) drives the same entry points as the
+    ctypes binding: identical index, bit-identical attention output."""
+    from vllm_trianglemix_amd import torch_ops
+    ops = _ops()
+    C = torch_ops.load()
+    H, Hkv, D, page = 8, 2, 128, 16
+    q_lens, seq_lens = [300, 1, 77], [300, 500, 130]
+    si, sl, last, chunk = 4, 32, 64, 4
+    q, ks, vs = _rand_case(555, q_lens, seq_lens, H, Hkv, D)
+    cu_h = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    sl_h = np.asarray(seq_lens, np.int32)
+    cu, sld = torch.from_numpy(cu_h).to(DEV), torch.from_numpy(sl_h).to(DEV)
+    nblk = sum((s + page - 1) // page for s in seq_lens)
+    perm = np.random.default_rng(1).permutation(nblk).astype(np.int32)
+    maxb = max((s + page - 1) // page for s in seq_lens)
+    bt = np.zeros((len(seq_lens), maxb), np.int32)
+    kc = torch.zeros((nblk, page, Hkv, D), dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    nxt = 0
+    slot_list = []
+    for b, s in enumerate(seq_lens):
+        for pb in range((s + page - 1) // page):
+            bt[b, pb] = perm[nxt]
+            nxt += 1
+        pos = np.arange(s)
+        slot_list.append(bt[b, pos // page].astype(np.int64) * page + pos % page)
+    slots = torch.from_numpy(np.concatenate(slot_list)).to(DEV)
+    C.trianglemix_reshape_and_cache(_to_dev(np.concatenate(ks, 0), torch.bfloat16),
+                                    _to_dev(np.concatenate(vs, 0), torch.bfloat16), kc, vc, slots)
+    btd = torch.from_numpy(bt).to(DEV)
+    bm, bn, mode = ops.attention_block_m(H, Hkv), ops.attention_block_n(), ops.MODES["triangle"]
+    R, nnz, n_items, n_part, n_split, _ = C.trianglemix_index_sizes(torch.from_numpy(cu_h), torch.from_numpy(sl_h), si,
+                                                                    sl, last, bm, bn, mode, 0, chunk)
+    i32 = lambda n: torch.empty((max(n, 1),), dtype=torch.int32, device=DEV)  # noqa: E731
+    index = [i32(R + 1), i32(nnz), i32(2 * R), i32(R + 1), i32(8 * n_items), i32(n_split), i32(8),
+             i32(len(seq_lens) + 1 + 2 * (R + 1))]
+    tile_pages = i32(2 * nnz)
+    C.trianglemix_build_block_index(index, tile_pages, cu, sld, torch.from_numpy(cu_h), torch.from_numpy(sl_h), btd,
+                                    page, si, sl, last, bm, bn, mode, 0, chunk)
+    ref_idx = ops.build_block_index(cu, sld, cu_h, sl_h, si, sl, last, bm, bn, mode, chunk_tiles=chunk,
+                                    block_table=btd, page_size=page)
+    assert torch.equal(index[0], ref_idx.row_ptr) and torch.equal(index[1][:nnz], ref_idx.col_idx)
+    assert torch.equal(index[4][:8 * n_items].view(-1, 8), ref_idx.items)
+    assert torch.equal(tile_pages[:2 * nnz].view(-1, 2), ref_idx.tile_pages)
+    qd = _to_dev(q, torch.bfloat16)
+    part_o = torch.empty((max(1, n_part * H * bm * D),), dtype=torch.float32, device=DEV)
+    part_ml = torch.empty((max(1, n_part * H * bm * 2),), dtype=torch.float32, device=DEV)
+    out_t = torch.full(qd.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
+    C.trianglemix_attention(out_t, qd, kc, vc, btd, cu, sld, None, index, tile_pages, part_o, part_ml, None,
+                            D ** -0.5, si, sl, last, mode, 0, chunk, n_items, n_part, n_split)
+    out_c = torch.full(qd.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.attention(qd, kc, vc, out_c, ref_idx, cu, sld, D ** -0.5, block_table=btd)
+    torch.cuda.synchronize()
+    assert torch.equal(out_t.view(torch.int16), out_c.view(torch.int16))
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu_h, seq_lens, D ** -0.5, "triangle", si, sl,
+                                   last)
+    got = out_t.float().cpu().numpy()
+    assert np.all(np.abs(got - ref) <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8)
+    with pytest.raises(RuntimeError, match="trianglemix"):
+        C.trianglemix_attention(out_t, qd, kc, vc, btd, cu, sld, None, index, tile_pages, part_o, part_ml, None,
+                                -1.0, si, sl, last, mode, 0, chunk, n_items, n_part, n_split)

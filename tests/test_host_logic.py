@@ -51,6 +51,19 @@ def test_struct_layouts_match_the_header():
     assert sizes == [ctypes.sizeof(_lib.IndexSizes), ctypes.sizeof(_lib.Index), ctypes.sizeof(_lib.AttentionArgs)]
 
 
+def test_torch_library_binding_registers_ops():
+    from vllm_trianglemix_amd import torch_ops
+    C = torch_ops.load()
+    for name in ("trianglemix_index_sizes", "trianglemix_build_block_index", "trianglemix_attention",
+                 "trianglemix_reshape_and_cache"):
+        assert hasattr(C, name)
+    cu, sl = torch.tensor([0, 100, 164], dtype=torch.int32), torch.tensor([100, 2500], dtype=torch.int32)
+    got = C.trianglemix_index_sizes(cu, sl, 4, 32, 64, 32, 32, ops.MODES["triangle"], 0, 32)
+    sz = ops.index_sizes(cu.numpy(), sl.numpy(), 4, 32, 64, 32, 32, ops.MODES["triangle"], chunk_tiles=32)
+    assert list(got) == [sz.num_qblocks, sz.nnz_tiles, sz.num_items, sz.num_partials, sz.num_split_qblocks,
+                         sz.max_tiles_per_qblock]
+
+
 @pytest.mark.parametrize("heads,kv,bm", [(32, 8, 32), (16, 8, 64), (8, 8, 128), (64, 8, 32), (4, 1, 32), (6, 2, 128)])
 def test_block_m_rule(heads, kv, bm):
     assert ops.attention_block_m(heads, kv) == bm

@@ -1,0 +1,205 @@
+// TORCH_LIBRARY binding of libtrianglemix_hip.so, in the style the reference registers its own
+// ROCm ops (csrc/rocm/torch_bindings.cpp:14-57, csrc/rocm/ops.h:17-26, csrc/core/registration.h:13-27):
+// schema strings with `Tensor!` for mutated outputs, implementations on the CUDA dispatch key (HIP
+// tensors dispatch there), outputs preallocated by the Python caller as vllm/_custom_ops.py:153-196
+// does.  Tensors are unpacked to the pointers, strides and sizes of the C ABI; the work is enqueued
+// on the current stream of the tensors' device; nothing synchronises with the host.
+//
+// Built as _trianglemix_C.so (plain C++, no device code) and loaded with
+// torch.ops.load_library(); the ops then live under torch.ops._trianglemix_C.
+#include <ATen/hip/HIPContext.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <optional>
+#include <vector>
+
+#include "trianglemix_hip.h"
+
+namespace {
+
+using at::Tensor;
+
+int dtype_code(const Tensor& t) {
+  switch (t.scalar_type()) {
+    case at::kFloat: return TMX_F32;
+    case at::kBFloat16: return TMX_BF16;
+    case at::kHalf: return TMX_F16;
+    default: TORCH_CHECK(false, "trianglemix: unsupported dtype ", t.scalar_type());
+  }
+}
+
+void check(int code) { TORCH_CHECK(code == TMX_OK, "trianglemix: ", tmx_last_error()); }
+
+void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+int32_t* i32(const Tensor& t) {
+  TORCH_CHECK(t.scalar_type() == at::kInt && t.is_contiguous(), "trianglemix: index tensors must be contiguous int32");
+  return t.data_ptr<int32_t>();
+}
+
+int32_t* i32_opt(const std::optional<Tensor>& t) { return t.has_value() ? i32(*t) : nullptr; }
+
+// The eight index buffers travel as one list: row_ptr, col_idx, qb_meta, part_ptr, items, split_qb, totals, scratch.
+void fill_index(tmx_index_t& ix, const std::vector<Tensor>& b, const std::optional<Tensor>& tile_pages,
+                const std::optional<Tensor>& pages_block_table, int64_t page_size, int64_t si, int64_t sl,
+                int64_t last, int64_t block_m, int64_t block_n, int64_t mode, int64_t tri_min_len,
+                int64_t chunk_tiles, int64_t batch) {
+  TORCH_CHECK(b.size() == 8, "trianglemix: the index is a list of 8 tensors");
+  ix = tmx_index_t{};
+  ix.row_ptr = i32(b[0]);
+  ix.col_idx = i32(b[1]);
+  ix.qb_meta = i32(b[2]);
+  ix.part_ptr = i32(b[3]);
+  ix.items = i32(b[4]);
+  ix.split_qb = i32(b[5]);
+  ix.totals = i32(b[6]);
+  ix.scratch = i32(b[7]);
+  ix.cap_qblocks = b[0].numel() - 1;
+  ix.cap_nnz = b[1].numel();
+  ix.cap_items = b[4].numel() / 8;
+  ix.cap_split = b[5].numel();
+  ix.block_m = (int32_t)block_m;
+  ix.block_n = (int32_t)block_n;
+  ix.mode = (int32_t)mode;
+  ix.chunk_tiles = (int32_t)chunk_tiles;
+  ix.si = (int32_t)si;
+  ix.sl = (int32_t)sl;
+  ix.last = (int32_t)last;
+  ix.batch = (int32_t)batch;
+  ix.tri_min_len = (int32_t)tri_min_len;
+  if (tile_pages.has_value() && pages_block_table.has_value()) {
+    ix.tile_pages = i32(*tile_pages);
+    TORCH_CHECK(pages_block_table->scalar_type() == at::kInt && pages_block_table->stride(1) == 1,
+                "trianglemix: block_table must be int32 with contiguous rows");
+    ix.pages_block_table = pages_block_table->data_ptr<int32_t>();
+    ix.pages_block_table_stride = pages_block_table->stride(0);
+    ix.pages_page_size = (int32_t)page_size;
+  }
+}
+
+// Exact buffer sizes from the host copies of the batch: [R, nnz, items, partials, split q-blocks, max tiles].
+std::vector<int64_t> index_sizes(const Tensor& cu_seqlens_q_cpu, const Tensor& seq_lens_cpu, int64_t si, int64_t sl,
+                                 int64_t last, int64_t block_m, int64_t block_n, int64_t mode, int64_t tri_min_len,
+                                 int64_t chunk_tiles) {
+  TORCH_CHECK(cu_seqlens_q_cpu.is_cpu() && seq_lens_cpu.is_cpu(), "trianglemix: host tensors expected");
+  tmx_index_sizes_t sz;
+  check(tmx_index_sizes(i32(cu_seqlens_q_cpu), i32(seq_lens_cpu), (int)seq_lens_cpu.numel(), (int)si, (int)sl,
+                        (int)last, (int)block_m, (int)block_n, (int)mode, (int)tri_min_len, (int)chunk_tiles, &sz));
+  return {sz.num_qblocks, sz.nnz_tiles, sz.num_items, sz.num_partials, sz.num_split_qblocks, sz.max_tiles_per_qblock};
+}
+
+void build_block_index(std::vector<Tensor> index, const std::optional<Tensor>& tile_pages, const Tensor& cu_seqlens_q,
+                       const Tensor& seq_lens, const Tensor& cu_seqlens_q_cpu, const Tensor& seq_lens_cpu,
+                       const std::optional<Tensor>& block_table, int64_t page_size, int64_t si, int64_t sl,
+                       int64_t last, int64_t block_m, int64_t block_n, int64_t mode, int64_t tri_min_len,
+                       int64_t chunk_tiles) {
+  const c10::hip::HIPGuard guard(cu_seqlens_q.device());
+  tmx_index_t ix;
+  fill_index(ix, index, tile_pages, block_table, page_size, si, sl, last, block_m, block_n, mode, tri_min_len,
+             chunk_tiles, seq_lens.numel());
+  check(tmx_build_block_index(&ix, i32(cu_seqlens_q), i32(seq_lens), i32(cu_seqlens_q_cpu), i32(seq_lens_cpu),
+                              stream_of(cu_seqlens_q)));
+}
+
+void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const Tensor& value_cache,
+               const std::optional<Tensor>& block_table, const Tensor& cu_seqlens_q, const Tensor& seq_lens,
+               const std::optional<Tensor>& cu_seqlens_k, std::vector<Tensor> index,
+               const std::optional<Tensor>& tile_pages, const std::optional<Tensor>& partial_o,
+               const std::optional<Tensor>& partial_ml, const std::optional<Tensor>& bias, double scale, int64_t si,
+               int64_t sl, int64_t last, int64_t mode, int64_t tri_min_len, int64_t chunk_tiles, int64_t num_items,
+               int64_t num_partials, int64_t num_split_qblocks) {
+  const c10::hip::HIPGuard guard(query.device());
+  TORCH_CHECK(query.dim() == 3 && out.dim() == 3, "trianglemix: query / out must be [T, H, D]");
+  const bool paged = block_table.has_value();
+  TORCH_CHECK(key_cache.dim() == (paged ? 4 : 3), "trianglemix: K/V must be [blocks, page, Hkv, D] (paged) or [rows, Hkv, D]");
+  tmx_index_t ix;
+  const int64_t hkv = key_cache.size(paged ? 2 : 1);
+  const int64_t block_m = tmx_attention_block_m((int)query.size(1), (int)hkv);
+  fill_index(ix, index, tile_pages, block_table, paged ? key_cache.size(1) : 0, si, sl, last, block_m,
+             tmx_attention_block_n(), mode, tri_min_len, chunk_tiles, seq_lens.numel());
+  tmx_attention_args_t a{};
+  a.struct_size = sizeof(a);
+  a.io_dtype = dtype_code(query);
+  a.out_dtype = dtype_code(out);
+  a.mode = (int32_t)mode;
+  a.si = (int32_t)si;
+  a.sl = (int32_t)sl;
+  a.last = (int32_t)last;
+  a.scale = (float)scale;
+  a.batch = (int32_t)seq_lens.numel();
+  a.num_heads = (int32_t)query.size(1);
+  a.num_kv_heads = (int32_t)hkv;
+  a.head_dim = (int32_t)query.size(2);
+  a.total_q = (int32_t)query.size(0);
+  a.out = out.data_ptr();
+  a.out_stride_t = out.stride(0);
+  a.out_stride_h = out.stride(1);
+  a.q = query.data_ptr();
+  a.q_stride_t = query.stride(0);
+  a.q_stride_h = query.stride(1);
+  a.k = key_cache.data_ptr();
+  a.v = value_cache.data_ptr();
+  if (paged) {
+    a.kv_stride_page = key_cache.stride(0);
+    a.kv_stride_t = key_cache.stride(1);
+    a.kv_stride_h = key_cache.stride(2);
+    a.block_table = i32(*block_table);
+    a.block_table_stride = block_table->stride(0);
+    a.page_size = (int32_t)key_cache.size(1);
+  } else {
+    TORCH_CHECK(cu_seqlens_k.has_value(), "trianglemix: contiguous K/V needs cu_seqlens_k");
+    a.kv_stride_t = key_cache.stride(0);
+    a.kv_stride_h = key_cache.stride(1);
+    a.cu_seqlens_k = i32(*cu_seqlens_k);
+  }
+  a.cu_seqlens_q = i32(cu_seqlens_q);
+  a.seq_lens = i32(seq_lens);
+  if (bias.has_value()) {
+    a.bias = bias->data_ptr();
+    a.bias_dtype = dtype_code(*bias);
+    a.bias_stride = bias->stride(0);
+    a.bias_rows = (int32_t)bias->size(0);
+    a.bias_cols = (int32_t)bias->size(1);
+  }
+  a.index = &ix;
+  a.num_items = num_items;
+  a.num_partials = num_partials;
+  a.num_split_qblocks = num_split_qblocks;
+  a.partial_o = partial_o.has_value() ? partial_o->data_ptr<float>() : nullptr;
+  a.partial_ml = partial_ml.has_value() ? partial_ml->data_ptr<float>() : nullptr;
+  check(tmx_attention(&a, stream_of(query)));
+}
+
+void reshape_and_cache(const Tensor& key, const Tensor& value, Tensor& key_cache, Tensor& value_cache,
+                       const Tensor& slot_mapping) {
+  const c10::hip::HIPGuard guard(key.device());
+  TORCH_CHECK(slot_mapping.scalar_type() == at::kLong && slot_mapping.is_contiguous(),
+              "trianglemix: slot_mapping must be contiguous int64");
+  const int64_t n = std::min<int64_t>(slot_mapping.numel(), key.size(0));
+  check(tmx_reshape_and_cache(key.data_ptr(), value.data_ptr(), key.stride(0), key.stride(1), key_cache.data_ptr(),
+                              value_cache.data_ptr(), key_cache.stride(0), key_cache.stride(1), key_cache.stride(2),
+                              slot_mapping.data_ptr<int64_t>(), (int32_t)n, (int32_t)key.size(1), (int32_t)key.size(2),
+                              (int32_t)key_cache.size(1), dtype_code(key), stream_of(key)));
+}
+
+}  // namespace
+
+TORCH_LIBRARY(_trianglemix_C, m) {
+  m.def("trianglemix_index_sizes(Tensor cu_seqlens_q_cpu, Tensor seq_lens_cpu, int si, int sl, int last, int block_m, "
+        "int block_n, int mode, int tri_min_len, int chunk_tiles) -> int[]");
+  m.impl("trianglemix_index_sizes", c10::DispatchKey::CPU, &index_sizes);
+  m.def("trianglemix_build_block_index(Tensor(a!)[] index, Tensor? tile_pages, Tensor cu_seqlens_q, Tensor seq_lens, "
+        "Tensor cu_seqlens_q_cpu, Tensor seq_lens_cpu, Tensor? block_table, int page_size, int si, int sl, int last, "
+        "int block_m, int block_n, int mode, int tri_min_len, int chunk_tiles) -> ()");
+  m.impl("trianglemix_build_block_index", c10::DispatchKey::CUDA, &build_block_index);
+  m.def("trianglemix_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, Tensor? block_table, "
+        "Tensor cu_seqlens_q, Tensor seq_lens, Tensor? cu_seqlens_k, Tensor[] index, Tensor? tile_pages, "
+        "Tensor? partial_o, Tensor? partial_ml, Tensor? bias, float scale, int si, int sl, int last, int mode, "
+        "int tri_min_len, int chunk_tiles, int num_items, int num_partials, int num_split_qblocks) -> ()");
+  m.impl("trianglemix_attention", c10::DispatchKey::CUDA, &attention);
+  m.def("trianglemix_reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, "
+        "Tensor slot_mapping) -> ()");
+  m.impl("trianglemix_reshape_and_cache", c10::DispatchKey::CUDA, &reshape_and_cache);
+}
