@@ -13,21 +13,24 @@ ap.add_argument("--heads", type=int, default=32)
 ap.add_argument("--kv", type=int, default=8)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--chunks", type=str, default="64")
+ap.add_argument("--dtype", type=str, default="bf16")
+ap.add_argument("--only", type=str, default="")
 ap.add_argument("--paged", type=int, default=1, help="0 contiguous, 1 paged with resolved pages, 2 paged with in-kernel lookups")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 n, H, Hkv, D = args.n, args.heads, args.kv, 128
 g = torch.Generator().manual_seed(0)
-q = torch.randn((n, H, D), generator=g).to(dev).bfloat16()
-k = torch.randn((n, Hkv, D), generator=g).to(dev).bfloat16()
-v = torch.randn((n, Hkv, D), generator=g).to(dev).bfloat16()
+DT = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+q = torch.randn((n, H, D), generator=g).to(dev).to(DT)
+k = torch.randn((n, Hkv, D), generator=g).to(dev).to(DT)
+v = torch.randn((n, Hkv, D), generator=g).to(dev).to(DT)
 out = torch.empty_like(q)
 cu_h, sl_h = np.asarray([0, n], np.int32), np.asarray([n], np.int32)
 cu, sl = torch.from_numpy(cu_h).to(dev), torch.from_numpy(sl_h).to(dev)
 PAGE = 16
 nblk = (n + PAGE - 1) // PAGE
 perm = torch.randperm(nblk, generator=g).to(torch.int32)
-kc = torch.zeros((nblk, PAGE, Hkv, D), dtype=torch.bfloat16, device=dev); vc = torch.zeros_like(kc)
+kc = torch.zeros((nblk, PAGE, Hkv, D), dtype=DT, device=dev); vc = torch.zeros_like(kc)
 pos = torch.arange(n)
 slots = (perm.long()[pos // PAGE] * PAGE + pos % PAGE).to(dev)
 ops.reshape_and_cache(k, v, kc, vc, slots)
@@ -45,7 +48,9 @@ def timed(fn, iters):
 bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
 algo = 2 * (H + Hkv) * D * 2 * n
 for name, (si, sl_, last), mode in (("triangle(4,32,64)", (4, 32, 64), "triangle"), ("stream only (last=0)", (4, 32, 0), "triangle"),
-                                     ("window only (si=-1,last=0)", (-1, 32, 0), "triangle"), ("diag+strip (si=-1,sl=0)", (-1, 0, 64), "triangle"), ("diag only (si=-1,sl=0,last=0)", (-1, 0, 0), "triangle"), ("causal", (0, 0, 0), "causal")):
+                                     ("window only (si=-1,last=0)", (-1, 32, 0), "triangle"), ("diag+strip (si=-1,sl=0)", (-1, 0, 64), "triangle"), ("diag only (si=-1,sl=0,last=0)", (-1, 0, 0), "triangle"), ("sink+diag (si=4,sl=0,last=0)", (4, 0, 0), "triangle"), ("sink31+diag (si=31,sl=0,last=0)", (31, 0, 0), "triangle"), ("causal", (0, 0, 0), "causal")):
+    if args.only and not any(name.startswith(o) for o in args.only.split(",")):
+        continue
     for chunk in [int(c) for c in args.chunks.split(",")]:
         if mode == "causal" and n > 16384 and args.iters > 3:
             iters = 3

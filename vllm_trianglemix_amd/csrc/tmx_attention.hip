@@ -49,6 +49,18 @@ struct Bf16Traits {
     return __builtin_bit_cast(short, h);
   }
   static __device__ __forceinline__ float to_float(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+  // 8 mantissa bits are too few for the probabilities: P = hi + lo, hi = p truncated to bf16 (exact
+  // remainder), lo = the remainder rounded to bf16; the second product doubles as error compensation.
+  static constexpr bool kSplitP = true;
+  static __device__ __forceinline__ void pack2(float p0, float p1, uint32_t& hi, uint32_t& lo) {
+    const uint32_t u0 = __float_as_uint(p0), u1 = __float_as_uint(p1);
+    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // (u1 & 0xffff0000) | (u0 >> 16)
+    const float r0 = p0 - __uint_as_float(u0 & 0xffff0000u), r1 = p1 - __uint_as_float(u1 & 0xffff0000u);
+    lo = (uint32_t)(uint16_t)cvt(r0) | ((uint32_t)(uint16_t)cvt(r1) << 16);
+  }
+  static __device__ __forceinline__ frag ones() {
+    return __builtin_bit_cast(frag, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+  }
 };
 
 struct F16Traits {
@@ -62,6 +74,14 @@ struct F16Traits {
   }
   static __device__ __forceinline__ float to_float(uint16_t b) {
     return (float)__builtin_bit_cast(_Float16, b);
+  }
+  static constexpr bool kSplitP = false;  // 11 mantissa bits: one term
+  static __device__ __forceinline__ void pack2(float p0, float p1, uint32_t& hi, uint32_t& lo) {
+    hi = (uint32_t)(uint16_t)cvt(p0) | ((uint32_t)(uint16_t)cvt(p1) << 16);
+    lo = 0;
+  }
+  static __device__ __forceinline__ frag ones() {
+    return __builtin_bit_cast(frag, make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u));
   }
 };
 
@@ -88,7 +108,7 @@ struct AttnParams {
   int kv_stride_page, kv_stride_t, kv_stride_h, block_table_stride;
   int64_t bias_stride;
   int page_size, page_shift;  // page_size is a power of two
-  int H, Hkv, G, Gw, block_m;
+  int H, Hkv, G, Gw, gw_shift, block_m;  // Gw = 1 << gw_shift query heads per workgroup
   int Y;                      // units per work item: K/V heads x head chunks
   int num_items;
   long long units_total;      // work items x Y
@@ -139,50 +159,6 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-// s_waitcnt takes an immediate: wait until at most `n` of this wave's vector-memory operations are
-// outstanding, rounded DOWN to a multiple of STEP and capped at 4 * STEP (waiting for fewer than
-// asked is always safe).  The common steady-state value is tested first.
-template <int STEP>
-__device__ __forceinline__ void wait_vmcnt_levels(int n) {
-  if (n >= 2 * STEP && n < 3 * STEP) wait_vmcnt<2 * STEP>();
-  else if (n >= 4 * STEP) wait_vmcnt<4 * STEP>();
-  else if (n >= 3 * STEP) wait_vmcnt<3 * STEP>();
-  else if (n >= STEP) wait_vmcnt<STEP>();
-  else wait_vmcnt<0>();
-}
-
-// One LDS-DMA instruction: every lane fetches 16 bytes from its own global
-// address; the wave's 1 KiB lands at LDS byte address lds_addr + 16 * lane.
-// Issued from inline asm on purpose: the compiler would otherwise wait for ALL
-// transfers in flight (vmcnt(0)) before every LDS read; here the waits are
-// counted by hand and followed by a workgroup barrier.
-// Form 1: per-lane 64-bit address.
-__device__ __forceinline__ void glds16(const void* src, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(src), "s"(lds_addr)
-      : "memory");
-}
-// Form 2: wave-uniform 64-bit base + per-lane 32-bit byte offset (no vector address arithmetic).
-__device__ __forceinline__ void glds16_s(const void* sbase, int voff, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(lds_addr)
-      : "memory");
-}
-
 // Diagnostic builds only (-DTMX_STAMPS): per-wave cycle sums of the loop's segments, written to a
 // buffer of their own.  No stamp executes in the shipped library.
 #ifdef TMX_STAMPS
@@ -205,17 +181,57 @@ constexpr float kMinusBig = -1.0e30f;
 // Workgroup shape of the attention kernel: 4 (head, 32-row) slots x 2 sixteen-row blocks = 8 waves
 // of 16 query rows each; all of them share the K/V tiles of one K/V head.
 constexpr int kWaves = 2 * kWavesPerWG;
-// Key tiles per softmax step: a step takes every remaining tile of the item when there are at most
-// kGroupMax of them (the sink + window items of the triangle pattern), otherwise 2.
-constexpr int kGroupMax = 2;
+// Key tiles per softmax step.
+constexpr int kGroupMax = 1;
+
+// One LDS-DMA instruction: every lane fetches 16 bytes from (wave-uniform 64-bit base + its own
+// 32-bit byte offset); the wave's 1 KiB lands at LDS byte address lds_addr + 16 * lane.
+// Issued from inline asm on purpose: the compiler would otherwise wait for ALL transfers in flight
+// (vmcnt(0)) before every LDS read; here the waits are counted by hand and followed by a barrier.
+__device__ __forceinline__ void glds16_s(const void* sbase, int voff, unsigned lds_addr) {
+  // wave-uniform operands are pinned to scalar registers (a uniform value the compiler happened
+  // to compute on the vector side would not assemble)
+  const unsigned long long b = (unsigned long long)(uintptr_t)sbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(sb), "s"(__builtin_amdgcn_readfirstlane(lds_addr))
+      : "memory", "m0");
+}
+// Per-lane 64-bit address form (ragged edges only).
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_addr) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, off"
+      :
+      : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr))
+      : "memory", "m0");
+}
+
+// s_waitcnt takes an immediate: wait until at most `n` of this wave's vector-memory operations are
+// outstanding, rounded DOWN to a multiple of STEP and capped at 4 * STEP (waiting for fewer than
+// asked is always safe).  The common steady-state value is tested first.
+template <int STEP>
+__device__ __forceinline__ void wait_vmcnt_levels(int n) {
+  if (n >= 2 * STEP && n < 3 * STEP) wait_vmcnt<2 * STEP>();
+  else if (n >= 4 * STEP) wait_vmcnt<4 * STEP>();
+  else if (n >= 3 * STEP) wait_vmcnt<3 * STEP>();
+  else if (n >= STEP) wait_vmcnt<STEP>();
+  else wait_vmcnt<0>();
+}
 
 // Persistent, software-pipelined kernel.  Every workgroup walks work items
 // item0, item0 + step, ... for ONE K/V head chunk and streams their inputs
 // through a ring of NS LDS entries of equal size: per item first 2 "Q entries"
 // (16 rows per wave each), then one entry per key tile ([K | V], 32 keys).
-// Entries are fetched by LDS-DMA up to NS entries ahead of their use, across
-// item boundaries, so the loads of the next item are in flight while the
-// current one is computed and stored.
+// Entries are fetched by LDS-DMA (every wave a fixed share of each entry) up
+// to NS entries ahead of their use, across item boundaries, so the loads of
+// the next item are in flight while the current one is computed and stored.
 template <typename TR, int D, int NS, bool PAGED, bool HAS_BIAS>
 __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p) {
   constexpr int KS = D / 32;            // k-steps of S^T = K Q^T
@@ -227,9 +243,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   constexpr int REGION = ENTRY / 4;     // one slot's 16 Q rows
   constexpr int RPP = 1024 / ROWB;      // rows per 1-KiB LDS-DMA piece (one wave instruction)
   constexpr int PE = ENTRY / 1024;      // pieces per entry
-  constexpr int PW = PE / kWaves;       // ... fetched by each wave
   constexpr int PT = PE / 2;            // ... per tensor of a K/V entry
   constexpr int PR = PE / 4;            // ... per Q region
+  constexpr int PW = PE / kWaves;       // ... fetched by each wave
+  constexpr bool PRECISE = TR::kSplitP; // P as a sum of two 16-bit terms
   static_assert(PW >= 1 && NS >= kGroupMax + 2, "ring too small");
   using frag = typename TR::frag;
 
@@ -243,8 +260,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds));
 
   const int sub = wave & 3, half = wave >> 2;
-  const int hg = sub % p.Gw;                  // this wave's head inside the workgroup's head group
-  const int rb16 = (sub / p.Gw) * 2 + half;   // its 16-row block inside the q-block
+  const int hg = sub & (p.Gw - 1);                  // this wave's head inside the workgroup's head group
+  const int rb16 = (sub >> p.gw_shift) * 2 + half;   // its 16-row block inside the q-block
   // fixed for the workgroup: K/V head and query heads (the grid is a multiple of Y, or has <= Y workgroups)
   const int kvc = blockIdx.x % p.Y;
   const int chunks = p.G / p.Gw;
@@ -285,12 +302,12 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   i32x4 ia0, ia1, ib0, ib1;
   int i_valid, ib_valid;
   auto fetch_item = [&](int k, i32x4& a0, i32x4& a1) -> int {
-    const long long item = item0 + (long long)k * item_step;
+    const int item = item0 + k * item_step;  // 32-bit on purpose: compared and indexed on the scalar unit
     const int ok = (item < p.num_items) && (k == 0 || item_step > 0);
     a0 = a1 = i32x4{0, 0, 0, 1};
     if (ok) {
-      a0 = sload(reinterpret_cast<const i32x4*>(p.items) + 2 * item);
-      a1 = sload(reinterpret_cast<const i32x4*>(p.items) + 2 * item + 1);
+      a0 = sload(reinterpret_cast<const i32x4*>(p.items) + 2ll * item);
+      a1 = sload(reinterpret_cast<const i32x4*>(p.items) + 2ll * item + 1);
     }
     return ok;
   };
@@ -433,6 +450,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     wait_vmcnt_levels<PW>(PW * (gi - gs - cnt) + (gs + cnt - 1 < store_mark ? store_ops : 0));
     TMX_STAMP(ts1);
 #ifndef TMX_ABLATE_BARRIER
+    // every LDS read of the entries about to be overwritten has returned before the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #endif
     TMX_STAMP(ts2);
@@ -491,6 +510,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         hole_width = w > 0 ? (unsigned)w : 0u;
       }
     }
+    // wave-uniform bounds: keys up to w_key_hi_min are below every row's key_hi; keys from
+    // w_hole_end_max on are past every row's hole
+    const int w_key_hi_min = (mode == TMX_MODE_NONE) ? n - 1 : imin(w_imin, n - 1);
+    const bool w_any_hole = mode == TMX_MODE_TRIANGLE && !w_all_last && (w_imax - p.sl > hole_lo + 1);
+    const int w_hole_end_max = w_imax - p.sl;  // exclusive end of the widest hole among the wave's rows
 
     f32x4 acc[DB];
 #pragma unroll
@@ -524,33 +548,30 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
         const int j0 = tl[u] * kBlockN, j1 = j0 + kBlockN - 1;
+        const int jl = j0 + koff_lane;
         if constexpr (HAS_BIAS) {
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            const int j = j0 + 16 * (c >> 2) + koff_lane + (c & 3);
+            const int j = jl + 16 * (c >> 2) + (c & 3);
             float b = 0.f;
             if (row_valid && j < p.bias_cols && pos_i < p.bias_rows && j <= key_hi)
               b = kLog2e * load_bias(p.bias, p.bias_dtype, (long long)pos_i * p.bias_stride + j);
             s[u][c >> 2][c & 3] = s[u][c >> 2][c & 3] * p.scale_log2 + b;
           }
         }
-        // `full`: every (row, key) pair of the wave's rows and this tile is attended (wave-uniform),
-        // so the per-element predicate is skipped.  Everything else goes through the predicate.
-        bool full;
-        if (mode == TMX_MODE_NONE) {
-          full = j1 < n;
-        } else {
-          full = j1 <= w_imin;
-          if (mode == TMX_MODE_TRIANGLE && !w_all_last) full = full && (j1 <= p.si || j0 >= w_imax - p.sl);
-        }
-        if (!full) {
-          const int jl = j0 + koff_lane;
+        // Two wave-uniform tests decide which parts of the predicate this tile needs at all.
+        if (j1 > w_key_hi_min) {  // some key may lie above some row's last key
+          const int d_hi = key_hi - jl;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            const int j = jl + 16 * (c >> 2) + (c & 3);
-            const bool in_hole = (unsigned)(j - hole_lo - 1) < hole_width;
-            s[u][c >> 2][c & 3] = (j <= key_hi && !in_hole) ? s[u][c >> 2][c & 3] : -__builtin_inff();
-          }
+          for (int c = 0; c < 8; ++c)
+            s[u][c >> 2][c & 3] = (16 * (c >> 2) + (c & 3) <= d_hi) ? s[u][c >> 2][c & 3] : -__builtin_inff();
+        }
+        if (w_any_hole && j1 > hole_lo && j0 < w_hole_end_max) {  // the tile meets some row's excluded section
+          const unsigned d_ho = (unsigned)(jl - hole_lo - 1);
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            s[u][c >> 2][c & 3] =
+                (d_ho + (unsigned)(16 * (c >> 2) + (c & 3)) < hole_width) ? -__builtin_inff() : s[u][c >> 2][c & 3];
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) tmax = fmaxf(tmax, s[u][c >> 2][c & 3]);
@@ -565,18 +586,20 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       const float m_new = fmaxf(m_run, tmax * mult);  // mult > 0
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
+      frag pf[CNT], pl[CNT];
       float psum = 0.f;
-      frag pf[CNT];
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
-        s16x8 pk;
+        uint32_t hi[4], lo[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][c >> 2][c & 3], mult, -m_new));
-          psum += pe;
-          pk[c] = TR::cvt(pe);
+        for (int c = 0; c < 8; c += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][c >> 2][c & 3], mult, -m_new));
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][c >> 2][(c & 3) + 1], mult, -m_new));
+          psum += p0 + p1;
+          TR::pack2(p0, p1, hi[c >> 1], lo[c >> 1]);
         }
-        pf[u] = __builtin_bit_cast(frag, pk);
+        pf[u] = __builtin_bit_cast(frag, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+        if constexpr (PRECISE) pl[u] = __builtin_bit_cast(frag, make_uint4(lo[0], lo[1], lo[2], lo[3]));
       }
       l_run = l_run * alpha + psum;
       if (!first && __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // wave-uniform: some row's maximum moved
@@ -589,12 +612,13 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int u = 0; u < CNT; ++u) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4*)(es[u] + (v_base ^ (32 * db))));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4*)(es[u] + 16 * ROWB + (v_base ^ (32 * db))));
-          const frag vf = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          const frag vf = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
           acc[db] = TR::mfma(vf, pf[u], acc[db]);
+          if constexpr (PRECISE) acc[db] = TR::mfma(vf, pl[u], acc[db]);
         }
       TMX_STAMP(ts1);
       TMX_SEG(3, ts0, ts1);
@@ -602,7 +626,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 
 #pragma unroll 1
     for (int t = 0; t < ntiles;) {
-      const int cnt = (ntiles - t <= kGroupMax) ? ntiles - t : 2;
+      const int cnt = imin(kGroupMax, ntiles - t);
       step_sync(cnt);
       int tl[kGroupMax];
 #pragma unroll
@@ -618,8 +642,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       const bool compute = w_has_rows;
 #endif
       if (compute) {
-        if (cnt == 3) process(std::integral_constant<int, 3>{}, tl, t == 0);
-        else if (cnt == 2) process(std::integral_constant<int, 2>{}, tl, t == 0);
+        if (cnt == 2) process(std::integral_constant<int, 2>{}, tl, t == 0);
         else process(std::integral_constant<int, 1>{}, tl, t == 0);
       }
       gs += cnt;
@@ -631,7 +654,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     // ---- epilogue: lane (qi, g) holds columns 16 * db + 4 * g .. +3 of its row for every db ----
     int stores = 0;
     if (w_has_rows) {
-      float l_tot;
+      float l_tot;  // sum over the 4 lanes that share a row
       {
         const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         l_tot = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
@@ -850,6 +873,7 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   TMX_CHECK_ARG(ix->mode == a->mode && ix->si == a->si && ix->sl == a->sl && ix->last == a->last &&
                     ix->batch == a->batch,
                 "tmx_attention: mask parameters differ from the ones the index was built with");
+  TMX_CHECK_SUPPORTED(a->num_items < (1ll << 30), "tmx_attention: more than 2^30 work items");
   TMX_CHECK_ARG(a->num_items <= ix->cap_items && a->num_split_qblocks <= ix->cap_split,
                 "tmx_attention: num_items / num_split_qblocks exceed the index capacities");
   TMX_CHECK_ARG(a->q && a->out && a->k && a->v && a->cu_seqlens_q && a->seq_lens, "tmx_attention: NULL tensor");
@@ -922,6 +946,7 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.Hkv = a->num_kv_heads;
   p.G = G;
   p.Gw = heads_per_wg(G);
+  p.gw_shift = __builtin_ctz(p.Gw);
   p.block_m = ix->block_m;
   p.mode = a->mode;
   p.si = a->si;

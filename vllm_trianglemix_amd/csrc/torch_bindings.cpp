@@ -7,9 +7,8 @@
 //
 // Built as _trianglemix_C.so (plain C++, no device code) and loaded with
 // torch.ops.load_library(); the ops then live under torch.ops._trianglemix_C.
-#include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include <optional>
@@ -32,7 +31,9 @@ int dtype_code(const Tensor& t) {
 
 void check(int code) { TORCH_CHECK(code == TMX_OK, "trianglemix: ", tmx_last_error()); }
 
-void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+// PyTorch-ROCm presents HIP devices under the "cuda" device type; these are its guard and stream types for them.
+using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
+void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 int32_t* i32(const Tensor& t) {
   TORCH_CHECK(t.scalar_type() == at::kInt && t.is_contiguous(), "trianglemix: index tensors must be contiguous int32");
@@ -95,7 +96,7 @@ void build_block_index(std::vector<Tensor> index, const std::optional<Tensor>& t
                        const std::optional<Tensor>& block_table, int64_t page_size, int64_t si, int64_t sl,
                        int64_t last, int64_t block_m, int64_t block_n, int64_t mode, int64_t tri_min_len,
                        int64_t chunk_tiles) {
-  const c10::hip::HIPGuard guard(cu_seqlens_q.device());
+  const DeviceGuard guard(cu_seqlens_q.device());
   tmx_index_t ix;
   fill_index(ix, index, tile_pages, block_table, page_size, si, sl, last, block_m, block_n, mode, tri_min_len,
              chunk_tiles, seq_lens.numel());
@@ -110,7 +111,7 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
                const std::optional<Tensor>& partial_ml, const std::optional<Tensor>& bias, double scale, int64_t si,
                int64_t sl, int64_t last, int64_t mode, int64_t tri_min_len, int64_t chunk_tiles, int64_t num_items,
                int64_t num_partials, int64_t num_split_qblocks) {
-  const c10::hip::HIPGuard guard(query.device());
+  const DeviceGuard guard(query.device());
   TORCH_CHECK(query.dim() == 3 && out.dim() == 3, "trianglemix: query / out must be [T, H, D]");
   const bool paged = block_table.has_value();
   TORCH_CHECK(key_cache.dim() == (paged ? 4 : 3), "trianglemix: K/V must be [blocks, page, Hkv, D] (paged) or [rows, Hkv, D]");
@@ -174,7 +175,7 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
 
 void reshape_and_cache(const Tensor& key, const Tensor& value, Tensor& key_cache, Tensor& value_cache,
                        const Tensor& slot_mapping) {
-  const c10::hip::HIPGuard guard(key.device());
+  const DeviceGuard guard(key.device());
   TORCH_CHECK(slot_mapping.scalar_type() == at::kLong && slot_mapping.is_contiguous(),
               "trianglemix: slot_mapping must be contiguous int64");
   const int64_t n = std::min<int64_t>(slot_mapping.numel(), key.size(0));
