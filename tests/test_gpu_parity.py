@@ -13,9 +13,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 # attention tolerance: fp32 kernel output vs the fp64 oracle on the same
-# 16-bit-rounded inputs.  P is rounded to 16 bits before the PV product, which
-# bounds the error by ~2^-9 * max|v| per row in the worst case.
-ATOL_F32_OUT = 1e-3 * 4
+# 16-bit-rounded inputs: 1e-3 absolute.  (bf16: the probabilities enter the PV
+# product as a sum of two bf16 terms, measured error ~2e-5; fp16: one fp16 term,
+# measured ~5e-4.)  A 16-bit OUTPUT adds its own rounding, 2^-8 relative.
+ATOL_F32_OUT = 1e-3
 
 
 def _pack(m):
@@ -282,7 +283,7 @@ def test_attention_matches_golden_eager(golden_attention):
         assert not np.isnan(got).any(), c["name"]
         err = np.abs(got - ref)
         # bf16 output: 1e-3 plus half an output ulp (2^-8 relative)
-        assert np.all(err <= 1e-3 * 4 + np.abs(ref) * 2.0 ** -8), (c["name"], err.max())
+        assert np.all(err <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8), (c["name"], err.max())
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -183,6 +183,8 @@ constexpr float kMinusBig = -1.0e30f;
 constexpr int kWaves = 2 * kWavesPerWG;
 // Key tiles per softmax step.
 constexpr int kGroupMax = 1;
+// The running row maximum is kept until a tile's maximum exceeds it by more than this (log2 units).
+constexpr float kMaxSlack = 8.0f;
 
 // One LDS-DMA instruction: every lane fetches 16 bytes from (wave-uniform 64-bit base + its own
 // 32-bit byte offset); the wave's 1 KiB lands at LDS byte address lds_addr + 16 * lane.
@@ -583,7 +585,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
         tmax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
       }
-      const float m_new = fmaxf(m_run, tmax * mult);  // mult > 0
+      // The running maximum only moves when the new one exceeds it by more than kMaxSlack (in log2
+      // units): probabilities may then reach 2^kMaxSlack instead of 1, which costs nothing in range
+      // or precision and saves most rescaling passes over the accumulator.
+      const float m_tile = tmax * mult;  // mult > 0
+      const float m_new = (m_tile > m_run + kMaxSlack) ? m_tile : m_run;
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
       frag pf[CNT], pl[CNT];
