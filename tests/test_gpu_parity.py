@@ -107,6 +107,35 @@ def test_generator_api_and_helper(golden_selection):
     assert ob.float().min().item() == torch.tensor(-1e6).bfloat16().float().item()
 
 
+def test_ascend_block_level_masks(golden_selection):
+    """Block-level variant: block masks vs the reference's own output, value conventions, thresholds."""
+    from vllm_trianglemix_amd.ascend_npu import (AscendBlockSparseMaskGenerator, AscendNPUTriangleMixAttention,
+                                                  AscendNPUTriangleMixConfig)
+    for rec in golden_selection["ascend_block"]:
+        cfg = AscendNPUTriangleMixConfig(rec["si"], rec["sl"], rec["last"], npu_block_size=rec["block"])
+        gen = AscendBlockSparseMaskGenerator(cfg)
+        bm = gen._get_block_sparse_mask(rec["n"], DEV, torch.float32)
+        got = bm.cpu().numpy()
+        assert list(got.shape) == rec["shape"] and int(got.sum()) == rec["nnz"]
+        assert hashlib.sha256(_pack(got)).hexdigest() == rec["sha256"]
+        tok = gen._expand_block_mask_to_token_level(bm, rec["n"], DEV, torch.float32).cpu().numpy()
+        want = np.kron(got, np.ones((rec["block"], rec["block"]), np.float32))[:rec["n"], :rec["n"]]
+        assert np.array_equal(tok, want)
+    cfg = AscendNPUTriangleMixConfig(num_triangle_layers=1)
+    helper = AscendNPUTriangleMixAttention(cfg, num_layers=2)
+    assert helper.get_attn_mask(512, 0, DEV) is None
+    m = helper.get_attn_mask(600, 0, DEV, torch.float32)            # triangle layer, token level below 2048
+    want = np.where(orc.triangle_mask(600, 4, 32, 64), 0.0, -1e9).astype(np.float32)
+    assert np.array_equal(m.cpu().numpy(), want)
+    mb = helper.get_attn_mask(4096, 0, DEV, torch.float32)           # triangle layer, block level above 2048
+    assert tuple(mb.shape) == (64, 64)
+    assert np.array_equal(mb.cpu().numpy(), np.where(orc.ascend_block_mask(4096, 4, 32, 64, 64) > 0, 0.0, -1e9)
+                          .astype(np.float32))
+    md = helper.get_attn_mask(5000, 1, DEV, torch.bfloat16)          # dense layer above 4096: 64-token blocks
+    assert tuple(md.shape) == (79, 79) and md.dtype == torch.bfloat16
+    assert np.array_equal(md.float().cpu().numpy() == 0, np.tril(np.ones((79, 79), bool)))
+
+
 # ------------------------------------------------------------------ index
 def _build(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk=4, gate=0, block_table=None, page_size=0):
     cu_h = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
@@ -301,6 +330,11 @@ def test_attention_varlen_gqa_vs_oracle(dtype):
         ([1, 1, 1], [700, 33, 1], 8, 2, 128, "triangle", (4, 32, 64)),
         ([40], [40], 3, 3, 64, "triangle", (0, 0, 0)),
         ([90], [90], 12, 2, 64, "triangle", (2, 5, 9)),
+        # per-GPU head shards of the tensor-parallel configurations: 32B at TP=4 (16 / 2 heads),
+        # 8B at TP=8 (4 / 1), 72B-shaped at TP=8 (8 / 1)
+        ([700], [700], 16, 2, 128, "triangle", (4, 32, 64)),
+        ([130, 40], [2300, 40], 4, 1, 128, "triangle", (4, 32, 64)),
+        ([333], [333], 8, 1, 128, "triangle", (4, 32, 64)),
     ]
     for ci, (ql, sl, H, Hkv, D, mode, pat) in enumerate(cases):
         q, ks, vs = _rand_case(1000 + ci, ql, sl, H, Hkv, D)

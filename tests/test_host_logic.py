@@ -145,6 +145,23 @@ def test_presets(golden_selection):
     assert tm(c) == p["custom_indices"]["tm_cfg"]
 
 
+def test_ascend_presets(golden_selection):
+    from vllm_trianglemix_amd.ascend_npu import (AscendBlockSparseMaskGenerator, AscendNPUTriangleMixAttention,
+                                                  create_ascend_trianglemix_config)
+    p = golden_selection["presets"]
+    for size in ("14B", "32B", "7B"):
+        cfg = create_ascend_trianglemix_config(size)
+        for k, v in p[f"ascend_{size}"].items():
+            assert getattr(cfg, k) == v, (size, k)
+    gen = AscendBlockSparseMaskGenerator(create_ascend_trianglemix_config("14B"))
+    assert gen.block_pattern() == (1, 1, 1)  # defaults at 64-token blocks: every parameter floors to 1
+    helper = AscendNPUTriangleMixAttention(create_ascend_trianglemix_config("14B"), num_layers=40)
+    assert helper.config.triangle_layer_indices == list(range(12))
+    assert helper.get_attn_mask(512, 0, torch.device("cpu")) is None  # no mask up to 512 tokens
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        helper.get_attn_mask(513, 0, torch.device("cpu"))
+
+
 def test_config_from_hf(golden_selection):
     for case in golden_selection["from_hf"]:
         hf = types.SimpleNamespace(**case["attrs"])
