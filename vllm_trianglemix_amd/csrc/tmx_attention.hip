@@ -754,28 +754,32 @@ __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p
   if (row >= imin(p.block_m, q_len - row0)) return;
   const long long stride = (long long)p.H * p.block_m;  // partial rows between consecutive pieces
   const long long prow0 = ((long long)slot0 * p.H + head) * p.block_m + row;
-  float M = kMinusBig, l = 0.f;
+  // pass 1 over the (max, sum) pairs: the common maximum; pass 2: weights, independent loads
+  const float2* mlp = reinterpret_cast<const float2*>(p.partial_ml) + prow0;
+  float M = kMinusBig;
+  for (int pc = 0; pc < np; ++pc) M = fmaxf(M, mlp[(long long)pc * stride].x);
+  float l = 0.f;
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int pc = 0; pc < np; pc += 4) {
-    float2 ml[4];
-    float4 v[4];
+  const float4* op = reinterpret_cast<const float4*>(p.partial_o + prow0 * D) + d4;
+  const long long ostride = stride * C4;  // float4 elements between consecutive pieces
+  constexpr int UN = 8;
+  for (int pc = 0; pc < np; pc += UN) {
+    float2 ml[UN];
+    float4 v[UN];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long long prow = prow0 + (long long)imin(pc + u, np - 1) * stride;
-      ml[u] = *reinterpret_cast<const float2*>(p.partial_ml + prow * 2);
-      v[u] = reinterpret_cast<const float4*>(p.partial_o + prow * D)[d4];
+    for (int u = 0; u < UN; ++u) {
+      const int q = imin(pc + u, np - 1);
+      ml[u] = mlp[(long long)q * stride];
+      v[u] = op[(long long)q * ostride];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (pc + u >= np) break;
-      const float Mn = fmaxf(M, ml[u].x);
-      const float a = __builtin_amdgcn_exp2f(M - Mn), w = __builtin_amdgcn_exp2f(ml[u].x - Mn);
-      M = Mn;
-      l = l * a + w * ml[u].y;
-      o.x = o.x * a + w * v[u].x;
-      o.y = o.y * a + w * v[u].y;
-      o.z = o.z * a + w * v[u].z;
-      o.w = o.w * a + w * v[u].w;
+    for (int u = 0; u < UN; ++u) {
+      const float w = (pc + u < np) ? __builtin_amdgcn_exp2f(ml[u].x - M) : 0.f;
+      l += w * ml[u].y;
+      o.x += w * v[u].x;
+      o.y += w * v[u].y;
+      o.z += w * v[u].z;
+      o.w += w * v[u].w;
     }
   }
   const float inv = 1.0f / l;  // every piece empty for this row: 0 * inf = NaN, as for an unsplit row

@@ -11,6 +11,10 @@
 //           exclusive scans (row_ptr, piece_ptr, part_ptr, split position).
 //   pass 2 (one wave per q-block): lanes write consecutive col_idx entries and
 //           the q-block's work items.
+// Up to 1024 q-blocks (a 32k-token prompt at block_m 32) the scan needs a single
+// round, every thread still holds its q-block's numbers, and pass 2 runs inside
+// the same launch: short tile lists are written by the owning thread, long ones
+// (the dense trailing rows) by the whole workgroup.
 #include "tmx_common.h"
 
 namespace tmx {
@@ -69,12 +73,55 @@ struct IndexParams {
   int32_t* piece_ptr;   // scratch [R + 1]
   int batch, block_m, block_n, mode, chunk, si, sl, last, tri_min_len;
   int cap_qblocks, cap_nnz, cap_items, cap_split;
+  int fused;  // pass 2 inside the scan launch (host: cap_qblocks <= 1024)
 };
 
+// Pass 2 for one q-block: entries e0, e0 + estep, ... of its tile list and pieces pc0, pc0 + estep, ...
+__device__ __forceinline__ void fill_qblock(const IndexParams& p, int qb, int b, int r0, int n, int ctx, int q_row0,
+                                            const TileRanges& tr, int cnt, int start, int first_item, int slot0,
+                                            int e0, int estep) {
+  for (int e = e0; e < cnt; e += estep)
+    if (start + e < p.cap_nnz) {
+      const int tile = tr.tile_at(e);
+      p.col_idx[start + e] = tile;
+      if (p.tile_pages != nullptr) {
+        // physical pages of the tile's two 16-key halves (keys past the end share the last page)
+        const int32_t* bt = p.block_table + (long long)b * p.block_table_stride;
+        int2 pg;
+        pg.x = bt[(tile * p.block_n) >> p.page_shift];
+        pg.y = bt[imin(tile * p.block_n + 16, n - 1) >> p.page_shift];
+        reinterpret_cast<int2*>(p.tile_pages)[start + e] = pg;
+      }
+    }
+  // work items: q-blocks descending, pieces ascending
+  const int pieces = imax(1, ceil_div(cnt, p.chunk));
+  for (int pc = e0; pc < pieces; pc += estep) {
+    const int it = first_item + pc;
+    if (it < p.cap_items) {
+      const int s = start + pc * p.chunk;
+      int4 rec;
+      rec.x = qb;
+      rec.y = s;
+      rec.z = imax(0, imin(p.chunk, start + cnt - s));
+      rec.w = pieces > 1 ? slot0 + pc : -1;
+      int4 geo;  // everything the attention kernel needs to place the q-block, so it reads nothing else
+      geo.x = b;
+      geo.y = q_row0;    // first row of the q-block in the packed q / out tensors
+      geo.z = ctx + r0;  // its position inside the sequence
+      geo.w = n;
+      reinterpret_cast<int4*>(p.items)[2 * it] = rec;
+      reinterpret_cast<int4*>(p.items)[2 * it + 1] = geo;
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
+  constexpr int kLongList = 16;  // tile lists longer than this are written by the whole workgroup
   __shared__ Int4 wave_sums[16];
   __shared__ int s_num_qblocks;
+  __shared__ int s_long[64], s_num_long;
   const int tid = threadIdx.x;
+  if (tid == 0) s_num_long = 0;
 
   // (a) q-blocks per request -> seq_qb_ptr
   int carry = 0;
@@ -130,6 +177,57 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
       if (v.w && e.w < p.cap_split) p.split_qb[e.w] = qb;
     }
     run = run + tot;
+    if (p.fused && R <= 1024) {
+      // single round: run holds the totals, this thread still holds its q-block's numbers
+      bool is_long = false;
+      if (qb < R && qb < p.cap_qblocks) {
+        const int ql = p.cu_q[b + 1] - p.cu_q[b];
+        const int n = p.seq_lens[b];
+        const int ctx = n - ql;
+        const int r1 = imin(r0 + p.block_m, ql);
+        const TileRanges tr = tile_ranges(effective_mode(p.mode, n, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, p.si,
+                                          p.sl, p.last, p.block_n);
+        is_long = v.x > kLongList;
+        if (!is_long)
+          fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, v.x, e.x, run.y - e.y - v.y, e.z, 0, 1);
+      }
+      if (is_long) {
+        const int at = atomicAdd(&s_num_long, 1);
+        if (at < 64) s_long[at] = qb;
+      }
+      __syncthreads();
+      const int num_long = s_num_long;
+      for (int k = 0; k < imin(num_long, 64); ++k) {
+        const int lq = s_long[k];
+        const int lb = p.qb_meta[2 * lq], lr0 = p.qb_meta[2 * lq + 1];  // written above by this workgroup
+        const int ql = p.cu_q[lb + 1] - p.cu_q[lb];
+        const int n = p.seq_lens[lb];
+        const int ctx = n - ql;
+        const int r1 = imin(lr0 + p.block_m, ql);
+        const TileRanges tr = tile_ranges(effective_mode(p.mode, n, p.tri_min_len), ctx + lr0, ctx + r1 - 1, n, p.si,
+                                          p.sl, p.last, p.block_n);
+        const int cnt = tr.count();
+        const int pieces = imax(1, ceil_div(cnt, p.chunk));
+        fill_qblock(p, lq, lb, lr0, n, ctx, p.cu_q[lb] + lr0, tr, cnt, p.row_ptr[lq],
+                    run.y - p.piece_ptr[lq] - pieces, p.part_ptr[lq], tid, 1024);
+      }
+      if (num_long > 64) {
+        // more long lists than the table holds: the remaining ones are written by their own threads
+        if (is_long) {
+          bool listed = false;
+          for (int k = 0; k < 64; ++k) listed = listed || s_long[k] == qb;
+          if (!listed) {
+            const int ql = p.cu_q[b + 1] - p.cu_q[b];
+            const int n = p.seq_lens[b];
+            const int ctx = n - ql;
+            const int r1 = imin(r0 + p.block_m, ql);
+            const TileRanges tr = tile_ranges(effective_mode(p.mode, n, p.tri_min_len), ctx + r0, ctx + r1 - 1, n,
+                                              p.si, p.sl, p.last, p.block_n);
+            fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, v.x, e.x, run.y - e.y - v.y, e.z, 0, 1);
+          }
+        }
+      }
+    }
   }
   // workgroup max of max_tiles (reuse the scan scratch)
   __syncthreads();
@@ -168,43 +266,9 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IndexParams p) {
   const int r1 = imin(r0 + p.block_m, ql);
   const TileRanges tr = tile_ranges(effective_mode(p.mode, n, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, p.si, p.sl, p.last, p.block_n);
   const int cnt = tr.count();
-  const int start = p.row_ptr[qb];
-  for (int e = lane; e < cnt; e += 64)
-    if (start + e < p.cap_nnz) {
-      const int tile = tr.tile_at(e);
-      p.col_idx[start + e] = tile;
-      if (p.tile_pages != nullptr) {
-        // physical pages of the tile's two 16-key halves (keys past the end share the last page)
-        const int32_t* bt = p.block_table + (long long)b * p.block_table_stride;
-        int2 pg;
-        pg.x = bt[(tile * p.block_n) >> p.page_shift];
-        pg.y = bt[imin(tile * p.block_n + 16, n - 1) >> p.page_shift];
-        reinterpret_cast<int2*>(p.tile_pages)[start + e] = pg;
-      }
-    }
-  // work items: q-blocks descending, pieces ascending
   const int pieces = imax(1, ceil_div(cnt, p.chunk));
-  const int total_pieces = p.piece_ptr[num_qblocks];
-  const int first_item = total_pieces - p.piece_ptr[qb] - pieces;
-  const int slot0 = p.part_ptr[qb];
-  for (int pc = lane; pc < pieces; pc += 64) {
-    const int it = first_item + pc;
-    if (it < p.cap_items) {
-      const int s = start + pc * p.chunk;
-      int4 rec;
-      rec.x = qb;
-      rec.y = s;
-      rec.z = imax(0, imin(p.chunk, start + cnt - s));
-      rec.w = pieces > 1 ? slot0 + pc : -1;
-      int4 geo;  // everything the attention kernel needs to place the q-block, so it reads nothing else
-      geo.x = b;
-      geo.y = p.cu_q[b] + r0;  // first row of the q-block in the packed q / out tensors
-      geo.z = ctx + r0;        // its position inside the sequence
-      geo.w = n;
-      reinterpret_cast<int4*>(p.items)[2 * it] = rec;
-      reinterpret_cast<int4*>(p.items)[2 * it + 1] = geo;
-    }
-  }
+  fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, cnt, p.row_ptr[qb],
+              p.piece_ptr[num_qblocks] - p.piece_ptr[qb] - pieces, p.part_ptr[qb], lane, 64);
 }
 
 }  // namespace tmx
@@ -280,10 +344,11 @@ extern "C" int tmx_build_block_index(tmx_index_t* idx, const int32_t* cu_q_dev, 
   p.cap_nnz = (int)idx->cap_nnz;
   p.cap_items = (int)idx->cap_items;
   p.cap_split = (int)idx->cap_split;
+  p.fused = idx->cap_qblocks <= 1024 ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   tmx::index_scan_kernel<<<1, 1024, 0, s>>>(p);
   TMX_CHECK_HIP(hipGetLastError());
-  if (idx->cap_qblocks > 0) {
+  if (idx->cap_qblocks > 0 && !p.fused) {
     const int nq = (int)idx->cap_qblocks;  // upper bound of the q-block count; surplus waves exit
     tmx::index_fill_kernel<<<tmx::ceil_div(nq, 4), 256, 0, s>>>(p);
     TMX_CHECK_HIP(hipGetLastError());
