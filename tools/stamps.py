@@ -26,7 +26,7 @@ pml = torch.zeros((max(need * 2, 1 << 20),), dtype=torch.float32, device=dev)
 for _ in range(3):
     ops.attention(q, k, v, out, idx, cu, sl, D ** -0.5, cu_seqlens_k=cu, workspace=(po, pml), flags=TMX_ATTN_SKIP_COMBINE)
 torch.cuda.synchronize()
-st = pml.view(torch.int64)[: 4096 * 4].view(-1, 4, 8).cpu().numpy()
+st = pml.view(torch.int64)[: 512 * 8 * 8].view(-1, 8, 8).cpu().numpy()  # [workgroup, wave, segment]
 st = st[st[:, 0, 6] > 0]
 names = ["wait", "barrier", "issue", "tile compute", "epilogue", "next unit", "TOTAL", "steps"]
 tot = st[:, :, 6].mean()
