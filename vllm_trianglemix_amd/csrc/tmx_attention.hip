@@ -228,31 +228,32 @@ __device__ __forceinline__ void wait_vmcnt_levels(int n) {
 }
 
 // Persistent, software-pipelined kernel.  Every workgroup walks work items
-// item0, item0 + step, ... for ONE K/V head chunk and streams their inputs
-// through a ring of NS LDS entries of equal size: per item first 2 "Q entries"
-// (16 rows per wave each), then one entry per key tile ([K | V], 32 keys).
-// Entries are fetched by LDS-DMA (every wave a fixed share of each entry) up
-// to NS entries ahead of their use, across item boundaries, so the loads of
-// the next item are in flight while the current one is computed and stored.
+// item0, item0 + step, ... for ONE K/V head chunk.  Their key tiles ([K | V],
+// 32 keys, one LDS entry each) stream through a ring of NS entries shared by
+// the workgroup, fetched by LDS-DMA (every wave a fixed share of each entry) up
+// to NS entries ahead of their use and across item boundaries.  The 16 query
+// rows of a wave are read by that wave alone, so they go through a private LDS
+// region per wave with no workgroup synchronisation: the rows of item k + 1 are
+// fetched as soon as the fragments of item k sit in registers.
 template <typename TR, int D, int NS, bool PAGED, bool HAS_BIAS>
 __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p) {
   constexpr int KS = D / 32;            // k-steps of S^T = K Q^T
   constexpr int DB = D / 16;            // 16-column output blocks
   constexpr int ROWB = D * 2;           // bytes per Q/K/V row in LDS
   constexpr int CPR = D / 8;            // 16-byte chunks per row
-  constexpr int ENTRY = 64 * ROWB;      // ring entry: K tile + V tile, or 4 slots x 16 Q rows
+  constexpr int ENTRY = 64 * ROWB;      // ring entry: K tile + V tile
   constexpr int HALF = ENTRY / 2;
-  constexpr int REGION = ENTRY / 4;     // one slot's 16 Q rows
+  constexpr int QREG = 16 * ROWB;       // a wave's private region: its 16 Q rows
+  constexpr int QP = QREG / 1024;       // LDS-DMA pieces of that region
   constexpr int RPP = 1024 / ROWB;      // rows per 1-KiB LDS-DMA piece (one wave instruction)
   constexpr int PE = ENTRY / 1024;      // pieces per entry
   constexpr int PT = PE / 2;            // ... per tensor of a K/V entry
-  constexpr int PR = PE / 4;            // ... per Q region
   constexpr int PW = PE / kWaves;       // ... fetched by each wave
   constexpr bool PRECISE = TR::kSplitP; // P as a sum of two 16-bit terms
-  static_assert(PW >= 1 && NS >= kGroupMax + 2, "ring too small");
+  static_assert(PW >= 1 && NS >= 3, "ring too small");
   using frag = typename TR::frag;
 
-  __shared__ __attribute__((aligned(16))) char lds[NS * ENTRY];
+  __shared__ __attribute__((aligned(16))) char lds[NS * ENTRY + kWaves * QREG];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -276,27 +277,28 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = 2 * p.kv_stride_t;
 
   // ---- LDS-DMA issue: wave-uniform bases + per-lane constant byte offsets ----
-  // Every wave fetches pieces wave * PW .. + PW - 1 of every entry.  In a Q entry they belong to
-  // slot `rq` (not the wave's own), in a K/V entry to one 16-key half of K or of V.
+  // Every wave fetches pieces wave * PW .. + PW - 1 of every K/V entry (one 16-key half of K or
+  // of V) and all QP pieces of its own Q region.
   const int piece_row = lane / CPR;  // row of this lane inside a 1-KiB piece
   const int piece_cc = lane % CPR;   // its 16-byte chunk
   const int pi0 = wave * PW;
-  const int rq = pi0 / PR;
-  const char* const q_iss = reinterpret_cast<const char*>(p.q) + 2ll * (head0 + rq % p.Gw) * p.q_stride_h;
-  const int q_iss_row0 = 32 * (rq / p.Gw);
-  const int pir0 = pi0 % PR;
   const bool iss_v = pi0 >= PT;
   const int pit0 = pi0 % PT;
   const bool iss_second = pit0 * RPP >= 16;  // keys 16..31 of the tile
   const char* const kv_iss =
       reinterpret_cast<const char*>(iss_v ? p.v : p.k) + 2ll * kvh * p.kv_stride_h;
-  int q_voff[PW], kv_voff[PW];
+  const char* const q_own = reinterpret_cast<const char*>(p.q) + 2ll * head * p.q_stride_h;
+  const unsigned q_lds = lds_base + NS * ENTRY + wave * QREG;
+  int kv_voff[PW], q_voff[QP];
 #pragma unroll
   for (int x = 0; x < PW; ++x) {
-    const int r16 = (pir0 + x) * RPP + piece_row;
-    q_voff[x] = r16 * q_row_bytes + 16 * (piece_cc ^ k_chunk_swizzle<D>(r16));
     const int row = (pit0 + x) * RPP + piece_row;
     kv_voff[x] = row * kv_row_bytes + 16 * (piece_cc ^ (iss_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row)));
+  }
+#pragma unroll
+  for (int x = 0; x < QP; ++x) {
+    const int r16 = x * RPP + piece_row;
+    q_voff[x] = r16 * q_row_bytes + 16 * (piece_cc ^ k_chunk_swizzle<D>(r16));
   }
 
   // ------------------------------------------------------------------ issue side (all scalar)
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   i_valid = fetch_item(0, ia0, ia1);
   ib_valid = fetch_item(1, ib0, ib1);
   int ik = 0;   // ordinal of the issue item among this workgroup's items
-  int ie = 0;   // its entries already issued
+  int ie = 0;   // its tiles already issued
   int gi = 0;   // entries issued so far
   int gi_slot = 0;  // gi mod NS
   // descriptor of the next K/V entry to issue, fetched one step ahead
@@ -326,8 +328,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 
   auto prefetch_desc = [&]() {
     // item fields: a0 = (qb, col_start, ntiles, slot), a1 = (b, q_tok0, pos0, n)
-    if (!i_valid || ie < 2 || ie >= 2 + ia0.z) return;
-    const int pos = ia0.y + (ie - 2);
+    if (!i_valid || ie >= ia0.z) return;
+    const int pos = ia0.y + ie;
     d_tile = sload(p.col_idx + pos);
     if constexpr (PAGED) {
       if (p.tile_pages != nullptr) {
@@ -342,29 +344,26 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     }
   };
 
+  // move the walk to the next item that has tiles
+  auto next_item_if_done = [&]() {
+#pragma unroll 1
+    while (i_valid && ie >= ia0.z) {
+      ia0 = ib0;
+      ia1 = ib1;
+      i_valid = ib_valid;
+      ++ik;
+      ib_valid = fetch_item(ik + 1, ib0, ib1);
+      ie = 0;
+      if constexpr (!PAGED) {
+        if (i_valid) i_krow0 = sload(p.cu_k + ia1.x);
+      }
+    }
+  };
+
   auto issue_one = [&]() {
     const unsigned dst = lds_base + (unsigned)gi_slot * ENTRY + pi0 * 1024;
     const int n = ia1.w;
-    if (ie < 2) {
-      // Q entry ie: rows 16 * ie .. + 15 of every slot's 32 rows
-      const int rows_valid = imin(p.block_m, n - ia1.z);
-      const int r0 = q_iss_row0 + 16 * ie;
-      if (r0 + 16 <= rows_valid) {
-        const char* sb = q_iss + (long long)(ia1.y + r0) * q_row_bytes;
-#pragma unroll
-        for (int x = 0; x < PW; ++x) glds16_s(sb, q_voff[x], dst + x * 1024);
-      } else {
-        // ragged last block: rows past the end of the request are never stored; read a valid row instead
-        const int l2 = opaque(lane);  // recomputed here: nothing of the rare path stays live in the main loop
-#pragma unroll
-        for (int x = 0; x < PW; ++x) {
-          const int r16 = (pir0 + x) * RPP + l2 / CPR;
-          const int r = imax(0, imin(r0 + r16, rows_valid - 1));
-          glds16(q_iss + (long long)(ia1.y + r) * q_row_bytes + 16 * ((l2 % CPR) ^ k_chunk_swizzle<D>(r16)),
-                 dst + x * 1024);
-        }
-      }
-    } else {
+    {
       const int j0 = d_tile * kBlockN;
       if (j0 + kBlockN <= n) {
         // whole tile inside the sequence: one wave-uniform base per 16-key half
@@ -399,26 +398,15 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     ++ie;
     ++gi;
     gi_slot = (gi_slot + 1 == NS) ? 0 : gi_slot + 1;
-    if (ie == 2 + ia0.z) {
-      ia0 = ib0;
-      ia1 = ib1;
-      i_valid = ib_valid;
-      ++ik;
-      ib_valid = fetch_item(ik + 1, ib0, ib1);
-      ie = 0;
-      if constexpr (!PAGED) {
-        if (i_valid) i_krow0 = sload(p.cu_k + ia1.x);
-      }
-    }
+    next_item_if_done();
     prefetch_desc();
   };
 
   if constexpr (!PAGED) {
     if (i_valid) i_krow0 = sload(p.cu_k + ia1.x);
   }
-#pragma unroll 1
-  for (int x = 0; x < NS; ++x)
-    if (i_valid) issue_one();
+  next_item_if_done();
+  prefetch_desc();
 
   // ------------------------------------------------------------------ compute side
   // per-lane LDS read offsets inside an entry: K / Q row qi, chunk 4 * ks + g is at k_base ^ (64 * ks)
@@ -437,6 +425,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   int gs_slot = 0;     // gs mod NS
   int store_mark = 0;  // entries below store_mark were issued before the last stores
   int store_ops = 0;   // vector-memory instructions of those stores (this wave)
+  int q_mark = 0;      // entries below q_mark were issued before the Q transfers in flight
+  int q_ops = 0;       // LDS-DMA instructions of those Q transfers (this wave)
+  int q_stores = 0;    // stores this wave issued after them
 
 #ifdef TMX_STAMPS
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -449,7 +440,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   // slots the previous step freed (entries below gs are consumed once every wave is past the barrier).
   auto step_sync = [&](int cnt) {
     TMX_STAMP(ts0);
-    wait_vmcnt_levels<PW>(PW * (gi - gs - cnt) + (gs + cnt - 1 < store_mark ? store_ops : 0));
+    wait_vmcnt_levels<PW>(PW * (gi - gs - cnt) + (gs + cnt - 1 < store_mark ? store_ops : 0) +
+                          (gs + cnt - 1 < q_mark ? q_ops : 0));
     TMX_STAMP(ts1);
 #ifndef TMX_ABLATE_BARRIER
     // every LDS read of the entries about to be overwritten has returned before the barrier
@@ -466,6 +458,49 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   };
   auto slot_after = [&](int s, int k) { return s + k >= NS ? s + k - NS : s + k; };
 
+  // Fetch this wave's 16 query rows of the item (a0, a1) into its private region.
+  auto issue_q = [&](const i32x4& a1) {
+    const int rows_valid = imin(p.block_m, a1.w - a1.z);
+    const int r0 = 16 * rb16;
+    q_mark = gi;
+    q_stores = 0;
+    q_ops = 0;
+    if (r0 >= rows_valid) return;  // no rows of this item for the wave
+    q_ops = QP;
+    if (r0 + 16 <= rows_valid) {
+      const char* sb = q_own + (long long)(a1.y + r0) * q_row_bytes;
+#pragma unroll
+      for (int x = 0; x < QP; ++x) glds16_s(sb, q_voff[x], q_lds + x * 1024);
+    } else {
+      // ragged last block: rows past the end of the request are never stored; read a valid row instead
+      const int l2 = opaque(lane);  // recomputed here: nothing of the rare path stays live in the main loop
+#pragma unroll
+      for (int x = 0; x < QP; ++x) {
+        const int r16 = x * RPP + l2 / CPR;
+        const int r = imin(r0 + r16, rows_valid - 1);
+        glds16(q_own + (long long)(a1.y + r) * q_row_bytes + 16 * ((l2 % CPR) ^ k_chunk_swizzle<D>(r16)),
+               q_lds + x * 1024);
+      }
+    }
+  };
+  // Wait for them: everything this wave issued later (tile pieces, stores) may stay in flight.
+  auto wait_q = [&]() {
+    const int n = PW * (gi - q_mark) + q_stores;
+    if (n >= 12) wait_vmcnt<12>();
+    else if (n >= 8) wait_vmcnt<8>();
+    else if (n >= 6) wait_vmcnt<6>();
+    else if (n >= 4) wait_vmcnt<4>();
+    else if (n >= 2) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+    q_ops = 0;
+  };
+
+  // prologue: the first item's query rows, then the ring
+  if (c_valid) issue_q(ca1);
+#pragma unroll 1
+  for (int x = 0; x < NS; ++x)
+    if (i_valid) issue_one();
+
   const float mult = HAS_BIAS ? 1.0f : p.scale_log2;  // factor between the accumulated scores and the exponent
 
   while (c_valid) {
@@ -479,17 +514,18 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 #pragma unroll
     for (int u = 0; u < kGroupMax; ++u) nt[u] = ntiles > 0 ? sload(p.col_idx + col_start + imin(u, ntiles - 1)) : 0;
 
-    // ---- Q fragments of this wave's 16 rows (B operand of S^T) ----
+    // ---- Q fragments of this wave's 16 rows (B operand of S^T), from the wave's private region ----
     frag qf[KS];
-    step_sync(2);
+    wait_q();
     {
-      const char* qs = lds + slot_after(gs_slot, half) * ENTRY + sub * REGION;
+      const char* qs = lds + NS * ENTRY + wave * QREG;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         qf[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(qs + (k_base ^ (64 * ks))));
     }
-    gs += 2;
-    gs_slot = slot_after(gs_slot, 2);
+    // the region is free again once the fragments are in registers: fetch the next item's rows
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf[0]), "+v"(qf[KS - 1])::"memory");
+    if (cb_valid) issue_q(cb1);
 
     // ---- wave-uniform row range of the wave's 16 rows, per-lane form of the predicate ----
     // key j is attended by this lane's row iff j <= key_hi and not (hole_lo < j < hole_lo + 1 + hole_width)
@@ -714,6 +750,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     }
     store_mark = gi;
     store_ops = stores;
+    q_stores += stores;
     TMX_STAMP(ts1);
     TMX_SEG(4, ts0, ts1);
 
@@ -800,7 +837,7 @@ __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p
   }
 }
 
-constexpr int kRingSlots = 5;  // LDS ring entries of the attention kernel
+constexpr int kRingSlots = 3;  // K/V ring entries of the attention kernel (plus a private Q region per wave)
 
 // Persistent grid: as many workgroups as stay resident (LDS and registers allow a fixed number per
 // CU), rounded down to a multiple of the units per item so that a workgroup keeps one K/V head.
