@@ -206,6 +206,8 @@ def main():
     bytes_per_token = 2 * (H + Hkv) * D * 2
     algo_bytes = bytes_per_token * batch * n
     achieved = algo_bytes / (t_attn_ms * 1e-3) / 1e9
+    # HBM-side bytes per launch of the same kernel on the same workload, from two rocprofv3 --pmc
+    # passes (FETCH_SIZE x 2 + WRITE_SIZE; tools/profile_round.sh writes the file); null when absent
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1:
@@ -214,7 +216,9 @@ def main():
         if tj.get("seq_len") == n and tj.get("kernel") == "attn_kernel":
             traffic = tj.get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "attn_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
+                "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": t_attn_ms, "combine_ms": t_comb_ms, "index_build_ms": t_index_ms}
 
     extra = {}
