@@ -400,12 +400,14 @@ def test_attention_bias_and_fully_masked_rows():
     assert np.abs(got2 - ref2).max() <= ATOL_F32_OUT
 
 
-def test_attention_linearity_in_v_at_full_size():
-    """Size-independent property at a BASELINE size (Qwen3-8B heads, N = 8192):
-    the output is linear in V, and rows inside the pattern's reach of a
-    constant V return that constant."""
+@pytest.mark.parametrize("n,paged", [(8192, False), (32768, True)])
+def test_attention_properties_at_full_size(n, paged):
+    """Size-independent properties at the BASELINE sizes (Qwen3-8B heads; N = 8192 contiguous K/V,
+    N = 32768 with the paged cache and shuffled block table of the benchmark): the output is linear
+    in V, a constant V returns that constant, and sampled rows (first rows, a middle row, rows
+    around the start of the dense trailing region, the last row) equal the oracle."""
     ops = _ops()
-    n, H, Hkv, D = 8192, 32, 8, 128
+    H, Hkv, D, page = 32, 8, 128, 16
     g = torch.Generator(device="cpu").manual_seed(0)
     q = torch.randn((n, H, D), generator=g).to(DEV).bfloat16()
     k = torch.randn((n, Hkv, D), generator=g).to(DEV).bfloat16()
@@ -413,27 +415,43 @@ def test_attention_linearity_in_v_at_full_size():
     v2 = torch.randn((n, Hkv, D), generator=g).to(DEV).bfloat16()
     cu_h, sl_h = np.asarray([0, n], np.int32), np.asarray([n], np.int32)
     cu, sld = torch.from_numpy(cu_h).to(DEV), torch.from_numpy(sl_h).to(DEV)
-    idx = ops.build_block_index(cu, sld, cu_h, sl_h, 4, 32, 64, ops.attention_block_m(H, Hkv), 32, 2)
+    bt = None
+    if paged:
+        nblk = n // page
+        perm = torch.randperm(nblk, generator=g).to(torch.int32)
+        bt = perm.view(1, -1).to(DEV)
+        pos = torch.arange(n)
+        slots = (perm.long()[pos // page] * page + pos % page).to(DEV)
+    idx = ops.build_block_index(cu, sld, cu_h, sl_h, 4, 32, 64, ops.attention_block_m(H, Hkv), 32, 2, chunk_tiles=32,
+                                block_table=bt, page_size=page if paged else 0)
     outs = []
     for v in (v1, v2, (v1.float() + v2.float()).bfloat16(), torch.ones_like(v1)):
         o = torch.empty((n, H, D), dtype=torch.float32, device=DEV)
-        ops.attention(q, k, v, o, idx, cu, sld, D ** -0.5, cu_seqlens_k=cu)
+        if paged:
+            kc = torch.zeros((n // page, page, Hkv, D), dtype=torch.bfloat16, device=DEV)
+            vc = torch.zeros_like(kc)
+            ops.reshape_and_cache(k, v, kc, vc, slots)
+            ops.attention(q, kc, vc, o, idx, cu, sld, D ** -0.5, block_table=bt)
+        else:
+            ops.attention(q, k, v, o, idx, cu, sld, D ** -0.5, cu_seqlens_k=cu)
         outs.append(o)
     lin = (outs[0] + outs[1] - outs[2]).abs().max().item()
     assert lin < 0.05  # v1 + v2 is re-rounded to bf16: 2^-8 relative on values up to ~8
-    assert (outs[3] - 1.0).abs().max().item() < 1e-2
-    # spot-check rows against the oracle (first, middle, last-region rows)
-    rows = [0, 5, 40, 4000, 8191 - 70, 8191 - 10, 8191]
+    assert (outs[3] - 1.0).abs().max().item() < 1e-5
+    assert not torch.isnan(outs[0]).any()
+    rows = [0, 5, 40, n // 2 + 17, n - 1 - 70, n - 64, n - 63, n - 10, n - 1]
     qn, kn, vn = q.float().cpu().numpy(), k.float().cpu().numpy(), v1.float().cpu().numpy()
     got = outs[0].cpu().numpy()
     for i in rows:
-        allow = orc.triangle_mask(n, 4, 32, 64)[i] if n <= 8192 else None
+        allow = np.zeros((n,), bool)
+        for lo, hi in orc.row_intervals(i, n, 4, 32, 64):
+            allow[lo:hi + 1] = True
         for h in (0, 13, 31):
             s = (kn[:, h // 4, :].astype(np.float64) @ qn[i, h].astype(np.float64)) * D ** -0.5
             s[~allow] = -np.inf
-            p = np.exp(s - s.max())
-            p /= p.sum()
-            assert np.abs(p @ vn[:, h // 4, :].astype(np.float64) - got[i, h]).max() <= ATOL_F32_OUT
+            pr = np.exp(s - s.max())
+            pr /= pr.sum()
+            assert np.abs(pr @ vn[:, h // 4, :].astype(np.float64) - got[i, h]).max() <= ATOL_F32_OUT, (i, h)
 
 
 def test_reshape_and_cache_and_errors():
