@@ -974,6 +974,9 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
                           a->kv_stride_page >= 0 && a->kv_stride_t >= 0 && a->kv_stride_h >= 0 &&
                           a->block_table_stride >= 0,
                       "tmx_attention: strides must be non-negative and below 2^31 elements");
+  // per-lane byte offsets inside a tile (32 rows) / a wave's query block (16 rows) are 32-bit
+  TMX_CHECK_SUPPORTED(a->kv_stride_t < (1ll << 24) && a->q_stride_t < (1ll << 24),
+                      "tmx_attention: row strides of q and k/v must be below 2^24 elements");
   p.q_stride_t = (int)a->q_stride_t;
   p.q_stride_h = (int)a->q_stride_h;
   p.out_stride_t = (int)a->out_stride_t;
