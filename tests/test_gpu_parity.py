@@ -355,6 +355,33 @@ def test_attention_varlen_gqa_vs_oracle(dtype):
             assert err <= ATOL_F32_OUT, (ci, paged, err)
 
 
+def test_attention_decode_heavy_batch():
+    """A serving-shaped step: 40 decode rows (one query each, contexts of 1 .. 3000 tokens, the
+    dense-causal last row of the pattern), two chunked-prefill continuations and one fresh prefill,
+    paged K/V with 16-token pages; every request is checked against the oracle."""
+    ops = _ops()
+    rng = np.random.default_rng(11)
+    H, Hkv, D = 8, 2, 128
+    seq_lens = [int(x) for x in rng.integers(1, 3000, size=40)] + [2600, 900, 350]
+    q_lens = [1] * 40 + [37, 64, 350]
+    q, ks, vs = _rand_case(9090, q_lens, seq_lens, H, Hkv, D)
+    scale = D ** -0.5
+    cu = np.concatenate([[0], np.cumsum(q_lens)])
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu, seq_lens, scale, "triangle", 4, 32, 64)
+    for chunk, gate in ((32, 0), (8, 2048)):
+        if gate:  # requests of at most 2048 tokens fall back to plain causal attention
+            ref_g = ref.copy()
+            for b, (ql, n) in enumerate(zip(q_lens, seq_lens)):
+                if n <= gate:
+                    ref_g[cu[b]:cu[b + 1]] = orc.varlen_gqa_attention(q[cu[b]:cu[b + 1]], lambda _: ks[b], lambda _: vs[b],
+                                                                      [0, ql], [n], scale, "causal", 0, 0, 0)
+        want = ref_g if gate else ref
+        got = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, "triangle", (4, 32, 64), paged=True, page_size=16,
+                          chunk=chunk, gate=gate)
+        assert not np.isnan(got).any()
+        assert np.abs(got - want).max() <= ATOL_F32_OUT, (chunk, gate, np.abs(got - want).max())
+
+
 def test_attention_split_and_combine_long():
     """One long prompt: trailing rows are split into many pieces and merged."""
     ops = _ops()
