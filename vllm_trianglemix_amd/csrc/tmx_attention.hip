@@ -39,8 +39,16 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
 struct Bf16Traits {
   using frag = bf16x8;
+  // two floats -> one dword of two bf16 (round to nearest even): one v_cvt_pk_bf16_f32
+  static __device__ __forceinline__ uint32_t cvt2(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+  }
   static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
@@ -56,7 +64,7 @@ struct Bf16Traits {
     const uint32_t u0 = __float_as_uint(p0), u1 = __float_as_uint(p1);
     hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // (u1 & 0xffff0000) | (u0 >> 16)
     const float r0 = p0 - __uint_as_float(u0 & 0xffff0000u), r1 = p1 - __uint_as_float(u1 & 0xffff0000u);
-    lo = (uint32_t)(uint16_t)cvt(r0) | ((uint32_t)(uint16_t)cvt(r1) << 16);
+    lo = cvt2(r0, r1);
   }
   static __device__ __forceinline__ frag ones() {
     return __builtin_bit_cast(frag, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
@@ -65,6 +73,9 @@ struct Bf16Traits {
 
 struct F16Traits {
   using frag = f16x8;
+  static __device__ __forceinline__ uint32_t cvt2(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
+  }
   static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
@@ -77,7 +88,7 @@ struct F16Traits {
   }
   static constexpr bool kSplitP = false;  // 11 mantissa bits: one term
   static __device__ __forceinline__ void pack2(float p0, float p1, uint32_t& hi, uint32_t& lo) {
-    hi = (uint32_t)(uint16_t)cvt(p0) | ((uint32_t)(uint16_t)cvt(p1) << 16);
+    hi = cvt2(p0, p1);
     lo = 0;
   }
   static __device__ __forceinline__ frag ones() {
