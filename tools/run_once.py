@@ -20,6 +20,7 @@ out = torch.empty_like(q)
 cu_h, sl_h = np.asarray([0, n], np.int32), np.asarray([n], np.int32)
 cu, sl = torch.from_numpy(cu_h).to(dev), torch.from_numpy(sl_h).to(dev)
 pat = {"triangle": (4, 32, 64, "triangle"), "stream": (4, 32, 0, "triangle"), "window": (-1, 32, 0, "triangle"),
+       "diag": (-1, 0, 0, "triangle"), "diagstrip": (-1, 0, 64, "triangle"),
        "causal": (0, 0, 0, "causal")}[mode]
 bt = None
 if paged:

@@ -45,6 +45,10 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 struct Bf16Traits {
   using frag = bf16x8;
+  // 16-key product: A / B hold 4 values per lane (keys 4 * (lane >> 4) .. + 3)
+  static __device__ __forceinline__ f32x4 mfma16(s16x4 a, uint2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+  }
   // two floats -> one dword of two bf16 (round to nearest even): one v_cvt_pk_bf16_f32
   static __device__ __forceinline__ uint32_t cvt2(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
@@ -73,6 +77,10 @@ struct Bf16Traits {
 
 struct F16Traits {
   using frag = f16x8;
+  static __device__ __forceinline__ f32x4 mfma16(s16x4 a, uint2 b, f32x4 c) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+  }
   static __device__ __forceinline__ uint32_t cvt2(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
   }
@@ -564,6 +572,12 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     const int w_key_hi_min = (mode == TMX_MODE_NONE) ? n - 1 : imin(w_imin, n - 1);
     const bool w_any_hole = mode == TMX_MODE_TRIANGLE && !w_all_last && (w_imax - p.sl > hole_lo + 1);
     const int w_hole_end_max = w_imax - p.sl;  // exclusive end of the widest hole among the wave's rows
+    // ... and for skipping 16-key half tiles no row of this wave attends to: a half [a, a + 15] is
+    // needed iff a <= w_key_max and, when every row of the wave has an excluded middle section,
+    // (a <= hole_lo  or  a + 15 >= w_window_min)
+    const int w_key_max = (mode == TMX_MODE_NONE) ? n - 1 : imin(w_imax, n - 1);
+    const bool w_all_holes = mode == TMX_MODE_TRIANGLE && !((n - w_imax) < p.last);
+    const int w_window_min = w_imin - p.sl;
 
     f32x4 acc[DB];
 #pragma unroll
@@ -571,9 +585,88 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     float m_run = kMinusBig, l_run = 0.f;
 
     // One softmax step over CNT key tiles (ring entries gs .. gs + CNT - 1).
+    // One softmax step over ONE 16-key half (kb) of the tile: the sink tile and the window's edge
+    // tiles of the sparse rows have a half that no row of the wave attends to.  Same arithmetic as the
+    // full step on half the keys; the second product uses the 16-key matrix instruction.
+    auto process_half = [&](int tile_no, int kb, bool first) {
+      const char* es = lds + gs_slot * ENTRY + kb * 16 * ROWB;
+      f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const frag kf = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(es + (k_base ^ (64 * ks))));
+        sc = TR::mfma(kf, qf[ks], sc);
+      }
+      const int ja = tile_no * kBlockN + 16 * kb, jb = ja + 15;
+      const int jl = ja + koff_lane;
+      if constexpr (HAS_BIAS) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int j = jl + c;
+          float b = 0.f;
+          if (row_valid && j < p.bias_cols && pos_i < p.bias_rows && j <= key_hi)
+            b = kLog2e * load_bias(p.bias, p.bias_dtype, (long long)pos_i * p.bias_stride + j);
+          sc[c] = sc[c] * p.scale_log2 + b;
+        }
+      }
+      if (jb > w_key_hi_min) {
+        const int d_hi = key_hi - jl;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sc[c] = (c <= d_hi) ? sc[c] : -__builtin_inff();
+      }
+      if (w_any_hole && jb > hole_lo && ja < w_hole_end_max) {
+        const unsigned d_ho = (unsigned)(jl - hole_lo - 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sc[c] = (d_ho + (unsigned)c < hole_width) ? -__builtin_inff() : sc[c];
+      }
+      float tmax = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+      {
+        const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+        const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+      }
+      const float m_tile = tmax * mult;
+      const float m_new = (m_tile > m_run + kMaxSlack) ? m_tile : m_run;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      uint2 ph, pl2;
+      float psum = 0.f;
+      {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[0], mult, -m_new));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[1], mult, -m_new));
+        const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2], mult, -m_new));
+        const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[3], mult, -m_new));
+        psum = (p0 + p1) + (p2 + p3);
+        TR::pack2(p0, p1, ph.x, pl2.x);
+        TR::pack2(p2, p3, ph.y, pl2.y);
+      }
+      l_run = l_run * alpha + psum;
+      if (!first && __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+        for (int db = 0; db < DB; ++db) acc[db] *= alpha;
+      }
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const s16x4 v4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(es + (v_base ^ (32 * db))));
+        acc[db] = TR::mfma16(v4, ph, acc[db]);
+        if constexpr (PRECISE) acc[db] = TR::mfma16(v4, pl2, acc[db]);
+      }
+    };
+
     auto process = [&](auto cnt_c, const int (&tl)[kGroupMax], bool first) {
       constexpr int CNT = decltype(cnt_c)::value;
       TMX_STAMP(ts0);
+      if constexpr (CNT == 1) {
+        const int a0 = tl[0] * kBlockN, a1 = a0 + 16;
+        const bool need0 = a0 <= w_key_max && (!w_all_holes || a0 <= hole_lo || a0 + 15 >= w_window_min);
+        const bool need1 = a1 <= w_key_max && (!w_all_holes || a1 <= hole_lo || a1 + 15 >= w_window_min);
+        if (!need0 && !need1) return;
+        if (need0 != need1) {
+          process_half(tl[0], need1 ? 1 : 0, first);
+          return;
+        }
+      }
       const char* es[CNT];
 #pragma unroll
       for (int u = 0; u < CNT; ++u) es[u] = lds + slot_after(gs_slot, u) * ENTRY;
