@@ -284,19 +284,53 @@ def gen_attention(mods, quick):
     return arrays, {"cases": meta, "gqa_in_eager_class": gqa}, timings
 
 
+def gen_config0(mods, gold):
+    """The reference's own CPU-runnable configuration (Qwen3-0.6B attention shape at 2048 tokens:
+    16 heads, head dim 128, defaults 4/32/64, fp32 run on bf16-rounded inputs) with the explicit
+    triangle mask.  Only sampled rows are kept (every 32nd row and the last 70)."""
+    tm, at = mods["trianglemix_attention"], mods["ascend_trianglemix"]
+    B, N, H, D, seed = 1, 2048, 16, 128, 21
+    q = orc.seeded_normal(seed * 3 + 0, (B, N, H, D))
+    k = orc.seeded_normal(seed * 3 + 1, (B, N, H, D))
+    v = orc.seeded_normal(seed * 3 + 2, (B, N, H, D))
+    cfg = tm.TriangleMixConfig(4, 32, 64)
+    gen = tm.TriangleMixMaskGenerator(cfg)
+    t0 = time.time()
+    am = gen.get_attention_mask(N, 0, torch.device("cpu"), torch.float32, use_triangle=True)
+    t_mask = time.time() - t0
+    mod = at.AscendTriangleMixAttention(H, D, D ** -0.5)
+    t0 = time.time()
+    out = mod(*(torch.from_numpy(x) for x in (q, k, v)), attn_mask=am)
+    t_attn = time.time() - t0
+    rows = sorted(set(range(0, N, 32)) | set(range(N - 70, N)))
+    np.savez_compressed(os.path.join(gold, "attention_config0.npz"), rows=np.asarray(rows, np.int32),
+                        out_rows=out[0, rows].numpy())
+    meta = {"B": B, "N": N, "H": H, "D": D, "seed": seed, "cfg": [4, 32, 64], "scale": D ** -0.5,
+            "inputs_sha256": hashlib.sha256(q.tobytes() + k.tobytes() + v.tobytes()).hexdigest(),
+            "mask_nnz": int((am == 0).sum()), "reference_mask_seconds": t_mask, "reference_attention_seconds": t_attn}
+    with open(os.path.join(gold, "attention_config0.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("config0 done", meta, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--quick", action="store_true", help="skip the N > 512 cases (minutes of Python loops)")
+    ap.add_argument("--config0-only", action="store_true", help="only (re)write attention_config0.*")
     args = ap.parse_args()
     mods = load_reference(args.reference)
     gold = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
     torch.set_num_threads(8)
+    if args.config0_only:
+        gen_config0(mods, gold)
+        return
 
     masks, t_mask = gen_masks(mods["trianglemix_attention"], args.quick)
     with open(os.path.join(gold, "masks.json"), "w") as f:
         json.dump({"cases": masks}, f, indent=0)
+    gen_config0(mods, gold)
     sel = gen_selection(mods, args.quick)
     with open(os.path.join(gold, "selection.json"), "w") as f:
         json.dump(sel, f, indent=0)

@@ -315,6 +315,31 @@ def test_attention_matches_golden_eager(golden_attention):
         assert np.all(err <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8), (c["name"], err.max())
 
 
+def test_attention_matches_reference_config0():
+    """The reference's own CPU-runnable configuration (2048 tokens, 16 heads, head dim 128, defaults
+    4/32/64) against the sampled rows of the reference's fp32 output: once through the index path
+    (pattern in the kernel) and once through the explicit-mask route of the eager mirror."""
+    import json, os
+    from vllm_trianglemix_amd import AscendTriangleMixAttention, TriangleMixConfig, TriangleMixMaskGenerator
+    ops = _ops()
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(gold, "attention_config0.json")))
+    z = np.load(os.path.join(gold, "attention_config0.npz"))
+    rows, want = z["rows"], z["out_rows"]
+    N, H, D, seed = meta["N"], meta["H"], meta["D"], meta["seed"]
+    q, k, v = (orc.seeded_normal(seed * 3 + t, (1, N, H, D)) for t in range(3))
+    assert hashlib.sha256(q.tobytes() + k.tobytes() + v.tobytes()).hexdigest() == meta["inputs_sha256"]
+    got = _run_varlen(ops, q[0], [k[0]], [v[0]], [N], [N], meta["scale"], "triangle", tuple(meta["cfg"]))
+    assert np.abs(got[rows] - want).max() <= ATOL_F32_OUT, np.abs(got[rows] - want).max()
+    gen = TriangleMixMaskGenerator(TriangleMixConfig(*meta["cfg"]))
+    am = gen.get_attention_mask(N, 0, DEV, torch.bfloat16, use_triangle=True)
+    assert int((am == 0).sum().item()) == meta["mask_nnz"]
+    mod = AscendTriangleMixAttention(H, D, meta["scale"])
+    out = mod(*(_to_dev(x, torch.bfloat16) for x in (q, k, v)), attn_mask=am)
+    got_b = out[0].float().cpu().numpy()
+    assert np.all(np.abs(got_b[rows] - want) <= ATOL_F32_OUT + np.abs(want) * 2.0 ** -8)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_attention_varlen_gqa_vs_oracle(dtype):
     ops = _ops()

@@ -258,3 +258,28 @@ def test_default_density_numbers():
     assert len(ci) == 2042
     rp, ci, _, _ = orc.block_index_closed_form([8192], [8192], 4, 32, 64, 64, 64, orc.MODE_TRIANGLE)
     assert len(ci) == 506
+
+
+def test_oracle_matches_reference_config0():
+    """The reference's own CPU-runnable configuration (2048 tokens, 16 heads, head dim 128, defaults):
+    oracle rows vs the sampled rows of the reference's output."""
+    import json, os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(gold, "attention_config0.json")))
+    z = np.load(os.path.join(gold, "attention_config0.npz"))
+    rows, want = z["rows"], z["out_rows"]
+    N, H, D, seed = meta["N"], meta["H"], meta["D"], meta["seed"]
+    q, k, v = (orc.seeded_normal(seed * 3 + t, (1, N, H, D)) for t in range(3))
+    assert orc.triangle_nnz(N, *meta["cfg"]) == meta["mask_nnz"]
+    for h in (0, 7, 15):
+        for r_i in (0, 1, len(rows) // 2, len(rows) - 64, len(rows) - 63, len(rows) - 1):
+            i = int(rows[r_i])
+            allow = np.zeros((N,), bool)
+            for lo, hi in orc.row_intervals(i, N, *meta["cfg"]):
+                allow[lo:hi + 1] = True
+            s_ = (k[0, :, h].astype(np.float64) @ q[0, i, h].astype(np.float64)) * meta["scale"]
+            s_[~allow] = -np.inf
+            pr = np.exp(s_ - s_.max())
+            pr /= pr.sum()
+            got = pr @ v[0, :, h].astype(np.float64)
+            assert np.abs(got - want[r_i, h]).max() < 2e-5, (i, h)
