@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 QWEN3_8B = dict(num_heads=32, num_kv_heads=8, head_dim=128, hidden=4096)
 PATTERN = (4, 32, 64)  # sink, window, last: the reference defaults
 PAGE = 16
-CHUNK_TILES = 32  # key tiles per work item of the dense trailing rows (32 x 32 = 1024 keys)
+CHUNK_TILES = 64  # key tiles per work item of the dense trailing rows (64 x 32 = 2048 keys)
 
 
 def parse():
