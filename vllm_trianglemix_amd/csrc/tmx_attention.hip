@@ -173,6 +173,14 @@ __device__ __forceinline__ int opaque(int x) {
   return x;
 }
 
+template <typename F>
+__device__ __forceinline__ F lds_read_b128(unsigned addr) {
+  return __builtin_bit_cast(F, *(const __attribute__((address_space(3))) uint4*)(uintptr_t)addr);
+}
+__device__ __forceinline__ s16x4 lds_read_tr16_b64(unsigned addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)addr);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   static_assert(PW >= 1 && NS >= 3, "ring too small");
   using frag = typename TR::frag;
 
-  __shared__ __attribute__((aligned(16))) char lds[NS * ENTRY + kWaves * QREG];
+  __shared__ __attribute__((aligned(1024))) char lds[NS * ENTRY + kWaves * QREG];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -320,10 +328,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     q_voff[x] = r16 * q_row_bytes + 16 * (piece_cc ^ k_chunk_swizzle<D>(r16));
   }
 
-  // ------------------------------------------------------------------ issue side (all scalar)
-  // current issue item and the one after it (fetched ahead)
-  i32x4 ia0, ia1, ib0, ib1;
-  int i_valid, ib_valid;
+  // ------------------------------------------------------------------ the workgroup's items
+  // item fields: a0 = (qb, col_start, ntiles, slot), a1 = (b, q_tok0, pos0, n)
   auto fetch_item = [&](int k, i32x4& a0, i32x4& a1) -> int {
     const int item = item0 + k * item_step;  // 32-bit on purpose: compared and indexed on the scalar unit
     const int ok = (item < p.num_items) && (k == 0 || item_step > 0);
@@ -334,54 +340,65 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     }
     return ok;
   };
-  i_valid = fetch_item(0, ia0, ia1);
-  ib_valid = fetch_item(1, ib0, ib1);
-  int ik = 0;   // ordinal of the issue item among this workgroup's items
-  int ie = 0;   // its tiles already issued
-  int gi = 0;   // entries issued so far
+  // the item being computed and the one after it
+  i32x4 ca0, ca1, cb0, cb1;
+  int c_valid = fetch_item(0, ca0, ca1);
+  int cb_valid = fetch_item(1, cb0, cb1);
+  int ck = 0;
+
+  // ------------------------------------------------------------------ issue side (all scalar)
+  // The issue cursor runs ahead of the compute side through the tile lists of the current item and of
+  // the next one, never further (an item shorter than the ring is deep leaves the ring less full):
+  // i_src = 0 / 1 names the item the cursor is in, 2 = nothing to issue until the compute side moves on.
+  int i_src = 2;
+  int i_pos = 0;    // next entry of col_idx to issue
+  int i_left = 0;   // tiles of the cursor's item not yet issued
+  int i_n = 1;      // its request: sequence length, index (block table)
+  int i_b = 0;
+  int gi = 0;       // entries issued so far
   int gi_slot = 0;  // gi mod NS
   // descriptor of the next K/V entry to issue, fetched one step ahead
   int d_tile = 0;
   long long d_off0 = 0, d_off1 = 0;  // byte offsets of the pages holding the tile's keys 0..15 / 16..31
-  long long i_krow0 = 0;             // contiguous K/V: first row of the issue item's request
+  long long i_krow0 = 0;             // contiguous K/V: first row of the cursor's request
+
+  auto cursor_to = [&](const i32x4& a0, const i32x4& a1, int src) {
+    i_src = src;
+    i_pos = a0.y;
+    i_left = a0.z;
+    i_n = a1.w;
+    i_b = a1.x;
+    if constexpr (!PAGED) i_krow0 = sload(p.cu_k + a1.x);
+  };
+  // leave exhausted lists behind
+  auto cursor_settle = [&]() {
+    if (i_src == 0 && i_left <= 0) {
+      if (cb_valid) cursor_to(cb0, cb1, 1);
+      else i_src = 2;
+    }
+    if (i_src == 1 && i_left <= 0) i_src = 2;
+  };
 
   auto prefetch_desc = [&]() {
-    // item fields: a0 = (qb, col_start, ntiles, slot), a1 = (b, q_tok0, pos0, n)
-    if (!i_valid || ie >= ia0.z) return;
-    const int pos = ia0.y + ie;
+    if (i_src == 2) return;
+    const int pos = i_pos;
     d_tile = sload(p.col_idx + pos);
     if constexpr (PAGED) {
       if (p.tile_pages != nullptr) {
         d_off0 = 2ll * sload(p.tile_pages + 2 * pos) * p.kv_stride_page;
         d_off1 = 2ll * sload(p.tile_pages + 2 * pos + 1) * p.kv_stride_page;
       } else {
-        const int32_t* bt = p.block_table + (long long)ia1.x * p.block_table_stride;
+        const int32_t* bt = p.block_table + (long long)i_b * p.block_table_stride;
         const int pg_first = (d_tile * kBlockN) >> p.page_shift;
         d_off0 = 2ll * sload(bt + pg_first) * p.kv_stride_page;
-        d_off1 = 2ll * sload(bt + (imin(d_tile * kBlockN + 16, ia1.w - 1) >> p.page_shift)) * p.kv_stride_page;
-      }
-    }
-  };
-
-  // move the walk to the next item that has tiles
-  auto next_item_if_done = [&]() {
-#pragma unroll 1
-    while (i_valid && ie >= ia0.z) {
-      ia0 = ib0;
-      ia1 = ib1;
-      i_valid = ib_valid;
-      ++ik;
-      ib_valid = fetch_item(ik + 1, ib0, ib1);
-      ie = 0;
-      if constexpr (!PAGED) {
-        if (i_valid) i_krow0 = sload(p.cu_k + ia1.x);
+        d_off1 = 2ll * sload(bt + (imin(d_tile * kBlockN + 16, i_n - 1) >> p.page_shift)) * p.kv_stride_page;
       }
     }
   };
 
   auto issue_one = [&]() {
     const unsigned dst = lds_base + (unsigned)gi_slot * ENTRY + pi0 * 1024;
-    const int n = ia1.w;
+    const int n = i_n;
     {
       const int j0 = d_tile * kBlockN;
       if (j0 + kBlockN <= n) {
@@ -414,17 +431,16 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         }
       }
     }
-    ++ie;
+    ++i_pos;
+    --i_left;
     ++gi;
     gi_slot = (gi_slot + 1 == NS) ? 0 : gi_slot + 1;
-    next_item_if_done();
+    cursor_settle();
     prefetch_desc();
   };
 
-  if constexpr (!PAGED) {
-    if (i_valid) i_krow0 = sload(p.cu_k + ia1.x);
-  }
-  next_item_if_done();
+  if (c_valid) cursor_to(ca0, ca1, 0);
+  cursor_settle();
   prefetch_desc();
 
   // ------------------------------------------------------------------ compute side
@@ -436,10 +452,6 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   const int v_base = HALF + v_row * ROWB + 8 * (lane & 3) + 32 * (v_chunk_swizzle<D>(v_row) >> 1);
   const int koff_lane = 4 * g;  // this lane's first key inside a 16-key half tile
 
-  i32x4 ca0, ca1, cb0, cb1;
-  int c_valid = fetch_item(0, ca0, ca1);
-  int cb_valid = fetch_item(1, cb0, cb1);
-  int ck = 0;
   int gs = 0;          // entries consumed so far
   int gs_slot = 0;     // gs mod NS
   int store_mark = 0;  // entries below store_mark were issued before the last stores
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 #endif
     TMX_STAMP(ts2);
 #pragma unroll 1
-    while (i_valid && gi - gs < NS) issue_one();
+    while (i_src != 2 && gi - gs < NS) issue_one();
     TMX_STAMP(ts3);
     TMX_SEG(0, ts0, ts1);
     TMX_SEG(1, ts1, ts2);
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   if (c_valid) issue_q(ca1);
 #pragma unroll 1
   for (int x = 0; x < NS; ++x)
-    if (i_valid) issue_one();
+    if (i_src != 2) issue_one();
 
   const float mult = HAS_BIAS ? 1.0f : p.scale_log2;  // factor between the accumulated scores and the exponent
 
@@ -589,11 +601,12 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     // tiles of the sparse rows have a half that no row of the wave attends to.  Same arithmetic as the
     // full step on half the keys; the second product uses the 16-key matrix instruction.
     auto process_half = [&](int tile_no, int kb, bool first) {
-      const char* es = lds + gs_slot * ENTRY + kb * 16 * ROWB;
+      const unsigned eb = lds_base + (unsigned)gs_slot * ENTRY + (unsigned)kb * 16 * ROWB;
+      const unsigned kl = eb + k_base, vl = eb + v_base;
       f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const frag kf = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(es + (k_base ^ (64 * ks))));
+        const frag kf = lds_read_b128<frag>(kl ^ (64 * ks));
         sc = TR::mfma(kf, qf[ks], sc);
       }
       const int ja = tile_no * kBlockN + 16 * kb, jb = ja + 15;
@@ -647,8 +660,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       }
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        const s16x4 v4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(es + (v_base ^ (32 * db))));
+        const s16x4 v4 = lds_read_tr16_b64(vl ^ (32 * db));
         acc[db] = TR::mfma16(v4, ph, acc[db]);
         if constexpr (PRECISE) acc[db] = TR::mfma16(v4, pl2, acc[db]);
       }
@@ -667,9 +679,13 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
           return;
         }
       }
-      const char* es[CNT];
+      unsigned kl[CNT], vl[CNT];
 #pragma unroll
-      for (int u = 0; u < CNT; ++u) es[u] = lds + slot_after(gs_slot, u) * ENTRY;
+      for (int u = 0; u < CNT; ++u) {
+        const unsigned eb = lds_base + (unsigned)slot_after(gs_slot, u) * ENTRY;
+        kl[u] = eb + k_base;
+        vl[u] = eb + v_base;
+      }
 
       // S^T = K Q^T for every tile of the group: 2 * CNT independent accumulator chains
       f32x4 s[CNT][2];
@@ -681,8 +697,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         for (int u = 0; u < CNT; ++u)
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb) {
-            const frag kf = __builtin_bit_cast(
-                frag, *reinterpret_cast<const uint4*>(es[u] + kb * 16 * ROWB + (k_base ^ (64 * ks))));
+            const frag kf = lds_read_b128<frag>((kl[u] ^ (64 * ks)) + kb * 16 * ROWB);
             s[u][kb] = TR::mfma(kf, qf[ks], s[u][kb]);
           }
 
@@ -758,10 +773,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int u = 0; u < CNT; ++u) {
-          const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(es[u] + (v_base ^ (32 * db))));
-          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(es[u] + 16 * ROWB + (v_base ^ (32 * db))));
+          const s16x4 lo4 = lds_read_tr16_b64(vl[u] ^ (32 * db));
+          const s16x4 hi4 = lds_read_tr16_b64((vl[u] ^ (32 * db)) + 16 * ROWB);
           const frag vf = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
           acc[db] = TR::mfma(vf, pf[u], acc[db]);
           if constexpr (PRECISE) acc[db] = TR::mfma(vf, pl[u], acc[db]);
@@ -863,6 +876,15 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     c_valid = cb_valid;
     ++ck;
     cb_valid = fetch_item(ck + 1, cb0, cb1);
+    // the cursor follows: what was the next item is the current one now; a cursor that had nothing left
+    // (the whole list of the new current item is issued) goes on into the new next item
+    if (i_src == 1) {
+      i_src = 0;
+    } else if (cb_valid) {
+      cursor_to(cb0, cb1, 1);
+      cursor_settle();
+      prefetch_desc();
+    }
     TMX_STAMP(ts2);
     TMX_SEG(5, ts1, ts2);
   }
