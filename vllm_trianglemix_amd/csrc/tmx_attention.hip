@@ -632,16 +632,26 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         for (int c = 0; c < 4; ++c) sc[c] = (d_ho + (unsigned)c < hole_width) ? -__builtin_inff() : sc[c];
       }
       float tmax = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-      {
+      // The running maximum only moves when some score exceeds it by more than kMaxSlack (log2 units): the
+      // test is per lane and wave-uniform, so the usual step has no cross-lane exchange and no rescaling.
+      float alpha = 1.f;
+      const bool moved = __builtin_amdgcn_ballot_w64(tmax * mult > m_run + kMaxSlack) != 0;
+      if (moved) {
         const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
         tmax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
         const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
         tmax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+        const float m_tile = tmax * mult;
+        const float m_new = (m_tile > m_run + kMaxSlack) ? m_tile : m_run;
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+        if (!first) {
+#pragma unroll
+          for (int db = 0; db < DB; ++db) acc[db] *= alpha;
+        }
       }
-      const float m_tile = tmax * mult;
-      const float m_new = (m_tile > m_run + kMaxSlack) ? m_tile : m_run;
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
+      const float m_new = m_run;
       uint2 ph, pl2;
       float psum = 0.f;
       {
@@ -653,11 +663,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         TR::pack2(p0, p1, ph.x, pl2.x);
         TR::pack2(p2, p3, ph.y, pl2.y);
       }
-      l_run = l_run * alpha + psum;
-      if (!first && __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
-#pragma unroll
-        for (int db = 0; db < DB; ++db) acc[db] *= alpha;
-      }
+      l_run += psum;
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
         const s16x4 v4 = lds_read_tr16_b64(vl ^ (32 * db));
@@ -733,20 +739,28 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 #pragma unroll
         for (int c = 0; c < 8; ++c) tmax = fmaxf(tmax, s[u][c >> 2][c & 3]);
       }
-      // maximum over the 4 lanes that share a row (lanes l, l ^ 16, l ^ 32, l ^ 48)
-      {
+      // The running maximum only moves when some score exceeds it by more than kMaxSlack (in log2
+      // units): probabilities may then reach 2^kMaxSlack instead of 1, which costs nothing in range
+      // or precision.  The test is per lane and wave-uniform, so the usual step has no cross-lane
+      // exchange and no rescaling pass over the accumulator.
+      const bool moved = __builtin_amdgcn_ballot_w64(tmax * mult > m_run + kMaxSlack) != 0;  // mult > 0
+      if (moved) {
+        // maximum over the 4 lanes that share a row (lanes l, l ^ 16, l ^ 32, l ^ 48)
         const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
         tmax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
         const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
         tmax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+        const float m_tile = tmax * mult;
+        const float m_next = (m_tile > m_run + kMaxSlack) ? m_tile : m_run;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_next);
+        m_run = m_next;
+        l_run *= alpha;
+        if (!first) {
+#pragma unroll
+          for (int db = 0; db < DB; ++db) acc[db] *= alpha;
+        }
       }
-      // The running maximum only moves when the new one exceeds it by more than kMaxSlack (in log2
-      // units): probabilities may then reach 2^kMaxSlack instead of 1, which costs nothing in range
-      // or precision and saves most rescaling passes over the accumulator.
-      const float m_tile = tmax * mult;  // mult > 0
-      const float m_new = (m_tile > m_run + kMaxSlack) ? m_tile : m_run;
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
+      const float m_new = m_run;
       frag pf[CNT], pl[CNT];
       float psum = 0.f;
 #pragma unroll
@@ -762,11 +776,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         pf[u] = __builtin_bit_cast(frag, make_uint4(hi[0], hi[1], hi[2], hi[3]));
         if constexpr (PRECISE) pl[u] = __builtin_bit_cast(frag, make_uint4(lo[0], lo[1], lo[2], lo[3]));
       }
-      l_run = l_run * alpha + psum;
-      if (!first && __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // wave-uniform: some row's maximum moved
-#pragma unroll
-        for (int db = 0; db < DB; ++db) acc[db] *= alpha;
-      }
+      l_run += psum;
 
       // O^T += V^T P^T (V fragments transposed by the LDS read)
 #pragma unroll
