@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TMX_ABI_VERSION 1
+#define TMX_ABI_VERSION 2
 
 enum {
   TMX_OK = 0,
@@ -105,6 +105,14 @@ int tmx_replace_neg_inf(void* mask_dev, int64_t count, int dtype, float value, v
  * by the combine pass of tmx_attention.  Unsplit q-blocks have slot -1.  Items
  * are ordered by q-block DESCENDING (the dense trailing rows start first),
  * pieces of one q-block ascending.
+ *
+ * Chunked prefill: the reference builds its mask for the whole sequence at
+ * once (N = seq_len, trianglemix_attention.py:126-129, 330-332).  When a
+ * prompt arrives in several steps, full_lens[b] (optional) is the length the
+ * sequence will have once its prompt is complete; N = max(seq_len[b],
+ * full_lens[b]) then decides the dense trailing rows (N - i < last) and the
+ * length gate, so that every step attends exactly as the one-step prefill
+ * of the whole prompt does.  Without full_lens, N = seq_len[b].
  * ---------------------------------------------------------------------- */
 typedef struct tmx_index_sizes_t {
   int64_t num_qblocks; /* R */
@@ -118,7 +126,8 @@ typedef struct tmx_index_sizes_t {
 /* Host-side sizing from the host mirrors of the batch (vLLM keeps them:
  * CommonAttentionMetadata.query_start_loc_cpu / seq_lens_cpu,
  * vllm/v1/attention/backends/utils.py:53-60).  No device work. */
-int tmx_index_sizes(const int32_t* cu_seqlens_q_host, const int32_t* seq_lens_host, int batch,
+int tmx_index_sizes(const int32_t* cu_seqlens_q_host, const int32_t* seq_lens_host,
+                    const int32_t* full_lens_host /* [batch] or NULL */, int batch,
                     int si, int sl, int last, int block_m, int block_n, int mode, int tri_min_len,
                     int chunk_tiles, tmx_index_sizes_t* out);
 
@@ -150,6 +159,9 @@ typedef struct tmx_index_t {
   int32_t* tile_pages;                /* (device) [nnz][2] or NULL */
   const int32_t* pages_block_table;   /* (device) [batch, pages_block_table_stride] or NULL */
   int64_t pages_block_table_stride;
+  /* Optional (see "Chunked prefill" above): set before the build, read again by tmx_attention. */
+  const int32_t* full_lens;           /* (device) [batch] or NULL */
+  const int32_t* full_lens_host;      /* host mirror, for the capacity check of the build; or NULL */
 } tmx_index_t;
 
 /* Builds the index on the device from the device copies of the batch

@@ -115,17 +115,22 @@ def middle_mask(n: int, si: int, sl: int, last: int) -> np.ndarray:
     return (i >= j) & ((n - i) >= last) & (j > si) & ((i - j) > sl)
 
 
-def triangle_mask(n: int, si: int, sl: int, last: int, q_len: Optional[int] = None) -> np.ndarray:
+def triangle_mask(n: int, si: int, sl: int, last: int, q_len: Optional[int] = None,
+                  n_full: Optional[int] = None) -> np.ndarray:
     """Closed form of the triangle mask (bool ``[q_len, n]``).
 
     ``allowed(i, j) = j <= i and (j <= si or i - j <= sl or n - i < last)``.
     With ``q_len < n`` the rows are the LAST ``q_len`` positions of the
     length-``n`` sequence (a query chunk that follows ``n - q_len`` cached
-    tokens), which is how the attention backend indexes rows.
+    tokens), which is how the attention backend indexes rows.  ``n_full > n``:
+    the rows and keys are the first ``n`` of a sequence whose mask is the one of
+    length ``n_full`` (a prompt still arriving in chunks): the result is the
+    block ``[n - q_len:n, :n]`` of the length-``n_full`` mask.
     """
     q_len = n if q_len is None else q_len
+    n_full = n if n_full is None else max(n, n_full)
     i, j = _ij(q_len, ctx=n - q_len, n_keys=n)
-    return (j <= i) & ((j <= si) | ((i - j) <= sl) | ((n - i) < last))
+    return (j <= i) & ((j <= si) | ((i - j) <= sl) | ((n_full - i) < last))
 
 
 def dense_mask(n: int, q_len: Optional[int] = None) -> np.ndarray:
@@ -258,7 +263,8 @@ def eager_attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: float,
 
 def varlen_gqa_attention(q: np.ndarray, k_rows, v_rows, cu_q: Sequence[int], seq_lens: Sequence[int],
                          scale: float, mode: str, si: int, sl: int, last: int,
-                         bias: Optional[np.ndarray] = None) -> np.ndarray:
+                         bias: Optional[np.ndarray] = None, full_lens: Optional[Sequence[int]] = None,
+                         tri_min_len: int = 0) -> np.ndarray:
     """Reference for the backend entry point: ragged batch, grouped heads.
 
     ``q`` is ``[T, H, D]``; request ``b`` owns rows ``cu_q[b]:cu_q[b+1]`` which
@@ -267,6 +273,10 @@ def varlen_gqa_attention(q: np.ndarray, k_rows, v_rows, cu_q: Sequence[int], seq
     backend tests, tests/v1/attention/test_attention_backends.py:376-380).
     ``k_rows(b)`` / ``v_rows(b)`` return ``[seq_len, Hkv, D]`` arrays (the
     caller resolves paging).  ``mode``: "triangle", "causal" or "none".
+    ``full_lens[b]``: length of the whole sequence the triangle pattern is
+    meant for (see :func:`triangle_mask`); ``tri_min_len``: sequences of at
+    most that (full) length are attended causally (the helper's length gate,
+    trianglemix_attention.py:330-332).
     Math is float64 (inputs are taken as given, i.e. already rounded).
     """
     t, h, d = q.shape
@@ -280,9 +290,10 @@ def varlen_gqa_attention(q: np.ndarray, k_rows, v_rows, cu_q: Sequence[int], seq
         vb = np.asarray(v_rows(b), dtype=np.float64)
         hkv = kb.shape[1]
         g = h // hkv
-        if mode == "triangle":
-            allow = triangle_mask(n, si, sl, last, q_len=ql)
-        elif mode == "causal":
+        nf = n if full_lens is None else max(n, int(full_lens[b]))
+        if mode == "triangle" and nf > tri_min_len:
+            allow = triangle_mask(n, si, sl, last, q_len=ql, n_full=nf)
+        elif mode in ("causal", "triangle"):
             allow = dense_mask(n, q_len=ql)
         else:
             allow = np.ones((ql, n), dtype=bool)
@@ -306,16 +317,16 @@ def varlen_gqa_attention(q: np.ndarray, k_rows, v_rows, cu_q: Sequence[int], seq
 MODE_NONE, MODE_CAUSAL, MODE_TRIANGLE = 0, 1, 2
 
 
-def _mode_mask(mode: int, n: int, ql: int, si: int, sl: int, last: int) -> np.ndarray:
+def _mode_mask(mode: int, n: int, ql: int, si: int, sl: int, last: int, n_full: Optional[int] = None) -> np.ndarray:
     if mode == MODE_TRIANGLE:
-        return triangle_mask(n, si, sl, last, q_len=ql)
+        return triangle_mask(n, si, sl, last, q_len=ql, n_full=n_full)
     if mode == MODE_CAUSAL:
         return dense_mask(n, q_len=ql)
     return np.ones((ql, n), dtype=bool)
 
 
 def block_index_bruteforce(q_lens: Sequence[int], seq_lens: Sequence[int], si: int, sl: int, last: int,
-                           bm: int, bn: int, mode: int):
+                           bm: int, bn: int, mode: int, full_lens: Optional[Sequence[int]] = None):
     """CSR block index straight from the token mask.
 
     The batch is cut into q-blocks of ``bm`` rows, request by request (a
@@ -330,7 +341,7 @@ def block_index_bruteforce(q_lens: Sequence[int], seq_lens: Sequence[int], si: i
     for b, (ql, n) in enumerate(zip(q_lens, seq_lens)):
         if ql == 0:
             continue
-        allow = _mode_mask(mode, n, ql, si, sl, last)
+        allow = _mode_mask(mode, n, ql, si, sl, last, None if full_lens is None else int(full_lens[b]))
         nt = (n + bn - 1) // bn
         for r0 in range(0, ql, bm):
             rows = allow[r0:min(r0 + bm, ql)]
@@ -344,17 +355,19 @@ def block_index_bruteforce(q_lens: Sequence[int], seq_lens: Sequence[int], si: i
             np.asarray(qb_seq, np.int32), np.asarray(qb_row0, np.int32))
 
 
-def qblock_tile_ranges(r0: int, r1: int, ql: int, n: int, si: int, sl: int, last: int, bn: int, mode: int):
+def qblock_tile_ranges(r0: int, r1: int, ql: int, n: int, si: int, sl: int, last: int, bn: int, mode: int,
+                       n_full: Optional[int] = None):
     """Closed form of one q-block's key-tile set: at most two inclusive tile
     ranges ``[(a0, a1), (b0, b1)]`` (second may be empty), ascending and
     disjoint.  Rows ``r0 .. r1-1`` of the request, positions ``ctx + r``."""
     ctx = n - ql
+    n_full = n if n_full is None else max(n, n_full)
     i_min, i_max = ctx + r0, ctx + r1 - 1
     nt = (n + bn - 1) // bn
     if mode == MODE_NONE:
         return [(0, nt - 1)] if nt > 0 else []
     t_diag = i_max // bn
-    if mode == MODE_CAUSAL or (mode == MODE_TRIANGLE and (n - i_max) < last):
+    if mode == MODE_CAUSAL or (mode == MODE_TRIANGLE and (n_full - i_max) < last):
         return [(0, t_diag)]
     ranges = []
     a_hi = min(i_max, si)
@@ -369,13 +382,14 @@ def qblock_tile_ranges(r0: int, r1: int, ql: int, n: int, si: int, sl: int, last
     return ranges
 
 
-def block_index_closed_form(q_lens, seq_lens, si, sl, last, bm, bn, mode):
+def block_index_closed_form(q_lens, seq_lens, si, sl, last, bm, bn, mode, full_lens=None):
     """Same result as :func:`block_index_bruteforce`, O(active tiles)."""
     row_ptr, col_idx, qb_seq, qb_row0 = [0], [], [], []
     for b, (ql, n) in enumerate(zip(q_lens, seq_lens)):
         for r0 in range(0, ql, bm):
             r1 = min(r0 + bm, ql)
-            for lo, hi in qblock_tile_ranges(r0, r1, ql, n, si, sl, last, bn, mode):
+            for lo, hi in qblock_tile_ranges(r0, r1, ql, n, si, sl, last, bn, mode,
+                                             None if full_lens is None else int(full_lens[b])):
                 col_idx.extend(range(lo, hi + 1))
             row_ptr.append(len(col_idx))
             qb_seq.append(b)

@@ -137,19 +137,23 @@ def test_ascend_block_level_masks(golden_selection):
 
 
 # ------------------------------------------------------------------ index
-def _build(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk=4, gate=0, block_table=None, page_size=0):
+def _build(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk=4, gate=0, block_table=None, page_size=0,
+           full_lens=None):
     cu_h = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
     sl_h = np.asarray(seq_lens, np.int32)
     cu = torch.from_numpy(cu_h).to(DEV)
     sld = torch.from_numpy(sl_h).to(DEV)
+    fl_h = None if full_lens is None else np.asarray(full_lens, np.int32)
+    fl = None if full_lens is None else torch.from_numpy(fl_h).to(DEV)
     idx = ops.build_block_index(cu, sld, cu_h, sl_h, si, sl, last, bm, bn, mode, chunk_tiles=chunk, tri_min_len=gate,
-                                block_table=block_table, page_size=page_size)
+                                block_table=block_table, page_size=page_size, full_lens=fl, full_lens_cpu=fl_h)
     return idx, cu, sld
 
 
-def _check_index(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk):
-    idx, _, _ = _build(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk)
-    row_ptr, col_idx, qb_seq, qb_row0 = orc.block_index_closed_form(q_lens, seq_lens, si, sl, last, bm, bn, mode)
+def _check_index(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk, full_lens=None):
+    idx, _, _ = _build(ops, q_lens, seq_lens, si, sl, last, bm, bn, mode, chunk, full_lens=full_lens)
+    row_ptr, col_idx, qb_seq, qb_row0 = orc.block_index_closed_form(q_lens, seq_lens, si, sl, last, bm, bn, mode,
+                                                                    full_lens)
     items, part_ptr = orc.work_items(row_ptr, chunk, qb_seq, qb_row0, q_lens, seq_lens)
     tot = idx.totals.cpu().numpy()
     assert tot[0] == len(row_ptr) - 1 == idx.sizes.num_qblocks
@@ -184,6 +188,14 @@ def test_block_index_bit_exact_vs_oracle():
         for bm, bn in ((16, 32), (64, 32), (32, 32), (64, 64)):
             for mode in (orc.MODE_TRIANGLE, orc.MODE_CAUSAL, orc.MODE_NONE):
                 _check_index(ops, ql, seq, si, sl, last, bm, bn, mode, chunk=3)
+    # chunked prefill: the pattern of the complete prompt (full length >= seq_len, or shorter: ignored)
+    for ql, seq, si, sl, last in cases[:12]:
+        full = [int(s + rng.integers(-5, 200)) for s in seq]
+        for bm in (16, 32):
+            _check_index(ops, ql, seq, si, sl, last, bm, 32, orc.MODE_TRIANGLE, chunk=3, full_lens=full)
+        bf = orc.block_index_bruteforce(ql, seq, si, sl, last, 16, 32, orc.MODE_TRIANGLE, full)
+        cf = orc.block_index_closed_form(ql, seq, si, sl, last, 16, 32, orc.MODE_TRIANGLE, full)
+        assert np.array_equal(bf[0], cf[0]) and np.array_equal(bf[1], cf[1])
     # bruteforce cross-check from the token bitmap (the definition of the index)
     for ql, seq, si, sl, last in cases[:8]:
         idx, _, _ = _build(ops, ql, seq, si, sl, last, 16, 32, orc.MODE_TRIANGLE)
@@ -218,7 +230,7 @@ def _to_dev(x, dtype):
 
 def _run_varlen(ops, q, k_list, v_list, q_lens, seq_lens, scale, mode, pattern, dtype=torch.bfloat16,
                 out_dtype=torch.float32, paged=False, page_size=16, bias=None, chunk=64, gate=0, q_pad=0,
-                resolve_pages=True):
+                resolve_pages=True, full_lens=None):
     """q: [T, H, D] float32 (already rounded); k_list/v_list: per-request [seq_len, Hkv, D]."""
     T, H, D = q.shape
     Hkv = k_list[0].shape[1]
@@ -226,7 +238,7 @@ def _run_varlen(ops, q, k_list, v_list, q_lens, seq_lens, scale, mode, pattern, 
     bm = ops.attention_block_m(H, Hkv)
     if not paged:
         idx, cu, sld = _build(ops, q_lens, seq_lens, si, sl, last, bm, ops.attention_block_n(), ops.MODES[mode],
-                              chunk, gate)
+                              chunk, gate, full_lens=full_lens)
     if q_pad:
         # rows of a wider buffer (as a slice of a fused qkv projection would be)
         buf = torch.zeros((T, H * D + q_pad), dtype=dtype, device=DEV)
@@ -253,7 +265,8 @@ def _run_varlen(ops, q, k_list, v_list, q_lens, seq_lens, scale, mode, pattern, 
                 vc[blk, :hi - lo] = _to_dev(v_list[b][lo:hi], dtype)
         btd = torch.from_numpy(bt).to(DEV)
         idx, cu, sld = _build(ops, q_lens, seq_lens, si, sl, last, bm, ops.attention_block_n(), ops.MODES[mode],
-                              chunk, gate, block_table=btd if resolve_pages else None, page_size=page_size)
+                              chunk, gate, block_table=btd if resolve_pages else None, page_size=page_size,
+                              full_lens=full_lens)
         if resolve_pages:
             # the resolved pages are the block-table entries of each listed tile's two halves
             tp = idx.tile_pages.cpu().numpy()
@@ -425,6 +438,49 @@ def test_attention_split_and_combine_long():
     gotc = _run_varlen(ops, q[:, :2].copy(), [ks[0][:, :1].copy()], [vs[0][:, :1].copy()], [n], [n], scale, "causal",
                        (0, 0, 0), chunk=16)
     assert np.abs(gotc - refc).max() <= ATOL_F32_OUT
+
+
+def test_chunked_prefill_equals_whole_prefill():
+    """A prompt that arrives in steps attends exactly as in one step when the steps know the prompt's
+    length: the trailing dense rows and the length gate refer to the whole prompt, not to the end of a
+    chunk.  Also a mixed step: a middle chunk, a decode row past its prompt, a last chunk."""
+    ops = _ops()
+    P, H, Hkv, D = 2500, 8, 2, 128
+    q, ks, vs = _rand_case(4242, [P], [P], H, Hkv, D)
+    scale = D ** -0.5
+    pat = (4, 32, 64)
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], [0, P], [P], scale, "triangle", *pat,
+                                   tri_min_len=2048)
+    whole = _run_varlen(ops, q, ks, vs, [P], [P], scale, "triangle", pat, paged=True, gate=2048)
+    assert np.abs(whole - ref).max() <= ATOL_F32_OUT
+    bounds = [0, 1000, 2040, 2467, P]  # the last-but-one chunk ends inside the dense trailing rows
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        got = _run_varlen(ops, q[lo:hi].copy(), [ks[0][:hi]], [vs[0][:hi]], [hi - lo], [hi], scale, "triangle", pat,
+                          paged=True, gate=2048, full_lens=[P])
+        assert np.abs(got - ref[lo:hi]).max() <= ATOL_F32_OUT, (lo, hi, np.abs(got - ref[lo:hi]).max())
+        want = orc.varlen_gqa_attention(q[lo:hi], lambda b: ks[0][:hi], lambda b: vs[0][:hi], [0, hi - lo], [hi], scale,
+                                        "triangle", *pat, full_lens=[P], tri_min_len=2048)
+        assert np.abs(want - ref[lo:hi]).max() < 1e-12  # the oracle itself: a chunk is a block of the whole
+        if hi < P - 64:
+            # without the prompt length the end of the chunk is taken for the end of the sequence
+            # (rows near it attend densely), or the chunk falls under the length gate: a different result
+            naive = _run_varlen(ops, q[lo:hi].copy(), [ks[0][:hi]], [vs[0][:hi]], [hi - lo], [hi], scale, "triangle",
+                                pat, paged=True, gate=2048)
+            assert np.abs(naive - ref[lo:hi]).max() > 10 * ATOL_F32_OUT
+    # mixed step: request 0 = middle chunk of a 2500-token prompt, request 1 = decode row 40 tokens past a
+    # 2100-token prompt (dense, as every decode row), request 2 = last chunk of a short prompt (gate: causal)
+    q_lens, seq_lens, full = [300, 1, 200], [1500, 2140, 700], [2500, 2100, 700]
+    q2, ks2, vs2 = _rand_case(777, q_lens, seq_lens, H, Hkv, D)
+    cu = np.concatenate([[0], np.cumsum(q_lens)])
+    want = orc.varlen_gqa_attention(q2, lambda b: ks2[b], lambda b: vs2[b], cu, seq_lens, scale, "triangle", *pat,
+                                    full_lens=full, tri_min_len=2048)
+    for paged in (True, False):
+        got = _run_varlen(ops, q2, ks2, vs2, q_lens, seq_lens, scale, "triangle", pat, paged=paged, gate=2048,
+                          full_lens=full)
+        assert np.abs(got - want).max() <= ATOL_F32_OUT
+    dense_row = orc.varlen_gqa_attention(q2[300:301], lambda b: ks2[1], lambda b: vs2[1], [0, 1], [2140], scale, "causal",
+                                         0, 0, 0)
+    assert np.abs(want[300:301] - dense_row).max() < 1e-12
 
 
 def test_attention_bias_and_fully_masked_rows():

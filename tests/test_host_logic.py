@@ -62,6 +62,11 @@ def test_torch_library_binding_registers_ops():
     sz = ops.index_sizes(cu.numpy(), sl.numpy(), 4, 32, 64, 32, 32, ops.MODES["triangle"], chunk_tiles=32)
     assert list(got) == [sz.num_qblocks, sz.nnz_tiles, sz.num_items, sz.num_partials, sz.num_split_qblocks,
                          sz.max_tiles_per_qblock]
+    full = torch.tensor([100, 4000], dtype=torch.int32)
+    got = C.trianglemix_index_sizes(cu, sl, 4, 32, 64, 32, 32, ops.MODES["triangle"], 0, 32, full)
+    sz = ops.index_sizes(cu.numpy(), sl.numpy(), 4, 32, 64, 32, 32, ops.MODES["triangle"], chunk_tiles=32,
+                         full_lens_cpu=full.numpy())
+    assert list(got)[:3] == [sz.num_qblocks, sz.nnz_tiles, sz.num_items] and sz.num_partials == 0
 
 
 @pytest.mark.parametrize("heads,kv,bm", [(32, 8, 32), (16, 8, 64), (8, 8, 128), (64, 8, 32), (4, 1, 32), (6, 2, 128)])
@@ -92,6 +97,25 @@ def test_index_sizes_match_oracle(mode, chunk):
         assert sz.num_partials == int(part_ptr[-1])
         assert sz.num_split_qblocks == int(np.count_nonzero(np.diff(part_ptr)))
         assert sz.max_tiles_per_qblock == int(np.max(np.diff(row_ptr)))
+        # chunked prefill: the pattern of the complete prompt
+        full = (seq + rng.integers(-3, 300, size=batch)).astype(np.int32)
+        szf = ops.index_sizes(cu, seq.astype(np.int32), si, sl, last, bm, bn, m, chunk_tiles=chunk, full_lens_cpu=full)
+        rp, ci, _, _ = orc.block_index_closed_form(qlen, seq, si, sl, last, bm, bn, m, full)
+        bf = orc.block_index_bruteforce(qlen, seq, si, sl, last, bm, bn, m, full)
+        assert np.array_equal(rp, bf[0]) and np.array_equal(ci, bf[1])
+        assert (szf.num_qblocks, szf.nnz_tiles) == (len(rp) - 1, len(ci))
+        assert szf.num_items == len(orc.work_items(rp, chunk)[0])
+
+
+def test_chunk_masks_are_blocks_of_the_whole_mask():
+    """Oracle: with the prompt's length known, the mask of a chunk (rows lo..hi-1, keys 0..hi-1) is the
+    corresponding block of the reference's mask of the whole prompt (trianglemix_attention.py:173-198)."""
+    for P, (si, sl, last) in ((300, (4, 32, 64)), (97, (0, 3, 10)), (130, (2, 0, 1))):
+        whole = orc.triangle_mask_loops(P, si, sl, last).astype(bool)
+        for lo, hi in ((0, P // 3), (P // 3, P - 20), (P - 20, P)):
+            assert np.array_equal(orc.triangle_mask(hi, si, sl, last, q_len=hi - lo, n_full=P), whole[lo:hi, :hi])
+        # a decode row past the prompt is dense-causal whatever the prompt length was
+        assert orc.triangle_mask(P + 9, si, sl, last, q_len=1, n_full=P).all() or last <= 1  # N - i = 1 < last
 
 
 def test_index_sizes_rejects_bad_input():
@@ -256,8 +280,14 @@ def test_metadata_builder_copies_host_description():
     assert md.page_size == 16 and md.num_actual_tokens == 7
     assert md.query_start_loc_cpu.dtype == np.int32 and md.query_start_loc_cpu.tolist() == [0, 3, 7]
     assert md.seq_lens_cpu.tolist() == [9, 4]
+    assert md.prompt_lens is None and md.prompt_lens_cpu is None
     with pytest.raises(NotImplementedError):
         builder.build(5, common)
+    # chunked prefill: a runner that passes the prompt lengths along gets the whole-prompt pattern
+    common.prompt_lens_cpu = torch.tensor([3000, 4], dtype=torch.int32)
+    md = builder.build(0, common)
+    assert md.prompt_lens_cpu.tolist() == [3000, 4] and md.prompt_lens.dtype == torch.int32
+    assert md.prompt_lens.tolist() == [3000, 4]
 
 
 # ------------------------------------------------------------------ head sharding rule

@@ -14,7 +14,7 @@ TMX_OK, TMX_ERR_INVALID_ARG, TMX_ERR_UNSUPPORTED, TMX_ERR_HIP, TMX_ERR_CAPACITY 
 TMX_F32, TMX_BF16, TMX_F16, TMX_FP8_E4M3 = range(4)
 TMX_MODE_NONE, TMX_MODE_CAUSAL, TMX_MODE_TRIANGLE = range(3)
 TMX_MASK_STREAMING, TMX_MASK_LAST, TMX_MASK_MIDDLE, TMX_MASK_TRIANGLE, TMX_MASK_DENSE = range(5)
-TMX_ABI_VERSION = 1
+TMX_ABI_VERSION = 2
 
 # every symbol include/trianglemix_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -43,7 +43,8 @@ class Index(Structure):
                 ("block_m", c_int32), ("block_n", c_int32), ("mode", c_int32), ("chunk_tiles", c_int32),
                 ("si", c_int32), ("sl", c_int32), ("last", c_int32), ("batch", c_int32),
                 ("tri_min_len", c_int32), ("pages_page_size", c_int32),
-                ("tile_pages", c_void_p), ("pages_block_table", c_void_p), ("pages_block_table_stride", c_int64)]
+                ("tile_pages", c_void_p), ("pages_block_table", c_void_p), ("pages_block_table_stride", c_int64),
+                ("full_lens", c_void_p), ("full_lens_host", c_void_p)]
 
 
 class AttentionArgs(Structure):
@@ -89,7 +90,7 @@ def load() -> ctypes.CDLL:
     lib.tmx_attention_block_n.argtypes = []
     lib.tmx_dense_mask.argtypes = [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.tmx_replace_neg_inf.argtypes = [c_void_p, c_int64, c_int, c_float, c_void_p]
-    lib.tmx_index_sizes.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+    lib.tmx_index_sizes.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     POINTER(IndexSizes)]
     lib.tmx_build_block_index.argtypes = [POINTER(Index), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.tmx_attention.argtypes = [POINTER(AttentionArgs), c_void_p]

@@ -58,6 +58,11 @@ class TriangleMixAttentionMetadata:
     page_size: int
     use_cascade: bool = False
     common_prefix_len: int = 0
+    # Chunked prefill: the length every request's sequence has once its prompt is complete (the runner
+    # knows it: gpu_model_runner.py:1189-1205 builds the batch from the requests' prompt lengths).  With it
+    # the trailing dense rows and the length gate refer to the whole prompt, as in a one-step prefill.
+    prompt_lens: Optional[torch.Tensor] = None       # int32 [B], device
+    prompt_lens_cpu: Optional[np.ndarray] = None     # int32 [B]
     _indices: Dict[Tuple, "ops.BlockIndex"] = field(default_factory=dict, repr=False)
     _workspaces: Dict[Tuple, tuple] = field(default_factory=dict, repr=False)
 
@@ -73,7 +78,8 @@ class TriangleMixAttentionMetadata:
             idx = ops.build_block_index(self.query_start_loc, self.seq_lens, self.query_start_loc_cpu,
                                         self.seq_lens_cpu, pattern[0], pattern[1], pattern[2], block_m,
                                         ops.attention_block_n(), ops.MODES[mode], tri_min_len=tri_min_len,
-                                        block_table=self.block_table, page_size=self.page_size)
+                                        block_table=self.block_table, page_size=self.page_size,
+                                        full_lens=self.prompt_lens, full_lens_cpu=self.prompt_lens_cpu)
             self._indices[key] = idx
         return idx
 
@@ -107,12 +113,19 @@ class TriangleMixMetadataBuilder:
         def host_i32(t):
             return np.ascontiguousarray(t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t), dtype=np.int32)
 
+        # optional extension of CommonAttentionMetadata (utils.py:44-84 has no such field): the prompt
+        # lengths of the scheduled requests, on the host
+        prompt_cpu = getattr(m, "prompt_lens_cpu", None)
+        prompt_dev = None
+        if prompt_cpu is not None:
+            prompt_cpu = host_i32(prompt_cpu)
+            prompt_dev = torch.from_numpy(prompt_cpu).to(m.seq_lens.device, non_blocking=True)
         return TriangleMixAttentionMetadata(
             num_actual_tokens=int(m.num_actual_tokens), max_query_len=int(m.max_query_len),
             query_start_loc=m.query_start_loc, max_seq_len=int(m.max_seq_len), seq_lens=m.seq_lens,
             block_table=m.block_table_tensor, slot_mapping=m.slot_mapping,
             query_start_loc_cpu=host_i32(m.query_start_loc_cpu), seq_lens_cpu=host_i32(m.seq_lens_cpu),
-            page_size=self.block_size)
+            page_size=self.block_size, prompt_lens=prompt_dev, prompt_lens_cpu=prompt_cpu)
 
     def build_for_cudagraph_capture(self, common_attn_metadata) -> TriangleMixAttentionMetadata:
         return self.build(0, common_attn_metadata)

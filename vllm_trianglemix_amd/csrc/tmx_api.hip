@@ -30,8 +30,8 @@ int tmx_attention_block_m(int num_heads, int num_kv_heads) {
 
 int tmx_attention_block_n(void) { return tmx::kBlockN; }
 
-int tmx_index_sizes(const int32_t* cu_q, const int32_t* seq_lens, int batch, int si, int sl, int last,
-                    int block_m, int block_n, int mode, int tri_min_len, int chunk_tiles,
+int tmx_index_sizes(const int32_t* cu_q, const int32_t* seq_lens, const int32_t* full_lens, int batch, int si,
+                    int sl, int last, int block_m, int block_n, int mode, int tri_min_len, int chunk_tiles,
                     tmx_index_sizes_t* out) {
   TMX_CHECK_ARG(out != nullptr, "tmx_index_sizes: out is NULL");
   TMX_CHECK_ARG(batch >= 0 && (batch == 0 || (cu_q && seq_lens)), "tmx_index_sizes: NULL batch arrays");
@@ -43,9 +43,12 @@ int tmx_index_sizes(const int32_t* cu_q, const int32_t* seq_lens, int batch, int
     const int n = seq_lens[b];
     TMX_CHECK_ARG(ql >= 0 && n >= ql, "tmx_index_sizes: request %d has q_len %d, seq_len %d", b, ql, n);
     const int ctx = n - ql;
+    const int nf = full_lens ? tmx::imax(n, full_lens[b]) : n;
     for (int r0 = 0; r0 < ql; r0 += block_m) {
       const int r1 = tmx::imin(r0 + block_m, ql);
-      const int cnt = tmx::tile_ranges(tmx::effective_mode(mode, n, tri_min_len), ctx + r0, ctx + r1 - 1, n, si, sl, last, block_n).count();
+      const int cnt =
+          tmx::tile_ranges(tmx::effective_mode(mode, nf, tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, si, sl, last, block_n)
+              .count();
       const int pieces = tmx::imax(1, tmx::ceil_div(cnt, chunk_tiles));
       ++R;
       nnz += cnt;

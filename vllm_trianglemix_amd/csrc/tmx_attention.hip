@@ -123,6 +123,7 @@ struct AttnParams {
   float* partial_ml;
   unsigned long long* stamps;  // diagnostic builds only
   const int32_t* tile_pages;   // [nnz][2] physical pages of each listed tile's halves, or NULL
+  const int32_t* full_lens;    // [batch] length of each sequence once its prompt is complete, or NULL
   int q_stride_t, q_stride_h, out_stride_t, out_stride_h;  // elements; checked to fit 31 bits
   int kv_stride_page, kv_stride_t, kv_stride_h, block_table_stride;
   int64_t bias_stride;
@@ -538,7 +539,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     const int col_start = ca0.y, ntiles = ca0.z, slot = ca0.w;
     const int q_tok0 = ca1.y, pos0 = ca1.z, n = ca1.w;
     const int rows_valid = imin(p.block_m, n - pos0);
-    const int mode = effective_mode(p.mode, n, p.tri_min_len);
+    // length of the whole sequence the pattern is meant for (chunked prefill: the complete prompt)
+    const int nf = p.full_lens != nullptr ? imax(n, sload(p.full_lens + ca1.x)) : n;
+    const int mode = effective_mode(p.mode, nf, p.tri_min_len);
 
     // tile numbers of the first group (clamped reads stay inside the item's list)
     int nt[kGroupMax];
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     const int w_row1 = imin(w_row0 + 16, rows_valid);
     const bool w_has_rows = w_row0 < rows_valid;
     const int w_imin = pos0 + w_row0, w_imax = pos0 + w_row1 - 1;
-    const bool w_all_last = (n - w_imin) < p.last;
+    const bool w_all_last = (nf - w_imin) < p.last;
     const int hole_lo = p.si < -1 ? -1 : p.si;
     const int my_row = w_row0 + qi;
     const bool row_valid = my_row < rows_valid;
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     unsigned hole_width = 0;
     if (row_valid) {
       key_hi = (mode == TMX_MODE_NONE) ? n - 1 : imin(pos_i, n - 1);
-      if (mode == TMX_MODE_TRIANGLE && !((n - pos_i) < p.last)) {
+      if (mode == TMX_MODE_TRIANGLE && !((nf - pos_i) < p.last)) {
         // keys si < j < pos_i - sl are the excluded middle section
         const long long w = (long long)pos_i - p.sl - (long long)hole_lo - 1;
         hole_width = w > 0 ? (unsigned)w : 0u;
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     // needed iff a <= w_key_max and, when every row of the wave has an excluded middle section,
     // (a <= hole_lo  or  a + 15 >= w_window_min)
     const int w_key_max = (mode == TMX_MODE_NONE) ? n - 1 : imin(w_imax, n - 1);
-    const bool w_all_holes = mode == TMX_MODE_TRIANGLE && !((n - w_imax) < p.last);
+    const bool w_all_holes = mode == TMX_MODE_TRIANGLE && !((nf - w_imax) < p.last);
     const int w_window_min = w_imin - p.sl;
 
     f32x4 acc[DB];
@@ -1122,6 +1125,7 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.kv_stride_h = (int)a->kv_stride_h;
   p.block_table_stride = (int)a->block_table_stride;
   p.tile_pages = nullptr;
+  p.full_lens = ix->full_lens;
   if (paged && ix->tile_pages != nullptr && ix->pages_block_table == a->block_table &&
       ix->pages_page_size == a->page_size && ix->pages_block_table_stride == a->block_table_stride)
     p.tile_pages = ix->tile_pages;

@@ -4,6 +4,8 @@
 // every kernel and by the host-side sizing code.  They follow the reference
 // predicate (vllm/attention/trianglemix_attention.py:82-89, 126-129, 192-196):
 //   allowed(i, j) = j <= i && (j <= si || i - j <= sl || N - i < last)
+// N is the length of the whole sequence the mask is meant for: the number of keys n, or, while a
+// prompt still arrives in chunks, the length it will have (n_full >= n).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -42,11 +44,11 @@ TMX_HD int effective_mode(int mode, int n, int tri_min_len) {
   return (mode == TMX_MODE_TRIANGLE && n <= tri_min_len) ? TMX_MODE_CAUSAL : mode;
 }
 
-TMX_HD bool allowed(int mode, int i, int j, int n, int si, int sl, int last) {
+TMX_HD bool allowed(int mode, int i, int j, int n_full, int si, int sl, int last) {
   if (mode == TMX_MODE_NONE) return true;
   if (j > i) return false;
   if (mode == TMX_MODE_CAUSAL) return true;
-  return j <= si || (i - j) <= sl || (n - i) < last;
+  return j <= si || (i - j) <= sl || (n_full - i) < last;
 }
 
 // Key-tile set of the query positions i_min..i_max (a q-block, or one wave's
@@ -62,7 +64,7 @@ struct TileRanges {
   TMX_HD bool contains(int t) const { return (t >= a0 && t <= a1) || (t >= b0 && t <= b1); }
 };
 
-TMX_HD TileRanges tile_ranges(int mode, int i_min, int i_max, int n, int si, int sl, int last, int bn) {
+TMX_HD TileRanges tile_ranges(int mode, int i_min, int i_max, int n, int n_full, int si, int sl, int last, int bn) {
   TileRanges r{0, -1, 0, -1};
   const int nt = ceil_div(n, bn);
   if (nt <= 0 || i_max < i_min) return r;
@@ -71,7 +73,7 @@ TMX_HD TileRanges tile_ranges(int mode, int i_min, int i_max, int n, int si, int
     return r;
   }
   const int t_diag = i_max / bn;
-  if (mode == TMX_MODE_CAUSAL || (n - i_max) < last) {
+  if (mode == TMX_MODE_CAUSAL || (n_full - i_max) < last) {
     r.a1 = t_diag;
     return r;
   }

@@ -58,6 +58,7 @@ __device__ Int4 block_exclusive_scan(Int4 v, Int4* wave_sums /* LDS [16] */, Int
 struct IndexParams {
   const int32_t* cu_q;
   const int32_t* seq_lens;
+  const int32_t* full_lens;  // [batch] or NULL: length each sequence will have once its prompt is complete
   int32_t* row_ptr;
   int32_t* col_idx;
   int32_t* qb_meta;
@@ -158,9 +159,10 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
       r0 = (qb - p.seq_qb_ptr[b]) * p.block_m;
       const int ql = p.cu_q[b + 1] - p.cu_q[b];
       const int n = p.seq_lens[b];
+      const int nf = p.full_lens ? imax(n, p.full_lens[b]) : n;
       const int ctx = n - ql;
       const int r1 = imin(r0 + p.block_m, ql);
-      const int cnt = tile_ranges(effective_mode(p.mode, n, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, p.si, p.sl, p.last, p.block_n).count();
+      const int cnt = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si, p.sl, p.last, p.block_n).count();
       const int pieces = imax(1, ceil_div(cnt, p.chunk));
       v = Int4{cnt, pieces, pieces > 1 ? pieces : 0, pieces > 1 ? 1 : 0};
       max_tiles = imax(max_tiles, cnt);
@@ -183,9 +185,10 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
       if (qb < R && qb < p.cap_qblocks) {
         const int ql = p.cu_q[b + 1] - p.cu_q[b];
         const int n = p.seq_lens[b];
+        const int nf = p.full_lens ? imax(n, p.full_lens[b]) : n;
         const int ctx = n - ql;
         const int r1 = imin(r0 + p.block_m, ql);
-        const TileRanges tr = tile_ranges(effective_mode(p.mode, n, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, p.si,
+        const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si,
                                           p.sl, p.last, p.block_n);
         is_long = v.x > kLongList;
         if (!is_long)
@@ -202,9 +205,10 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
         const int lb = p.qb_meta[2 * lq], lr0 = p.qb_meta[2 * lq + 1];  // written above by this workgroup
         const int ql = p.cu_q[lb + 1] - p.cu_q[lb];
         const int n = p.seq_lens[lb];
+        const int nf = p.full_lens ? imax(n, p.full_lens[lb]) : n;
         const int ctx = n - ql;
         const int r1 = imin(lr0 + p.block_m, ql);
-        const TileRanges tr = tile_ranges(effective_mode(p.mode, n, p.tri_min_len), ctx + lr0, ctx + r1 - 1, n, p.si,
+        const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + lr0, ctx + r1 - 1, n, nf, p.si,
                                           p.sl, p.last, p.block_n);
         const int cnt = tr.count();
         const int pieces = imax(1, ceil_div(cnt, p.chunk));
@@ -219,9 +223,10 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
           if (!listed) {
             const int ql = p.cu_q[b + 1] - p.cu_q[b];
             const int n = p.seq_lens[b];
+            const int nf = p.full_lens ? imax(n, p.full_lens[b]) : n;
             const int ctx = n - ql;
             const int r1 = imin(r0 + p.block_m, ql);
-            const TileRanges tr = tile_ranges(effective_mode(p.mode, n, p.tri_min_len), ctx + r0, ctx + r1 - 1, n,
+            const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf,
                                               p.si, p.sl, p.last, p.block_n);
             fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, v.x, e.x, run.y - e.y - v.y, e.z, 0, 1);
           }
@@ -262,9 +267,10 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IndexParams p) {
   const int b = p.qb_meta[2 * qb], r0 = p.qb_meta[2 * qb + 1];
   const int ql = p.cu_q[b + 1] - p.cu_q[b];
   const int n = p.seq_lens[b];
+  const int nf = p.full_lens ? imax(n, p.full_lens[b]) : n;
   const int ctx = n - ql;
   const int r1 = imin(r0 + p.block_m, ql);
-  const TileRanges tr = tile_ranges(effective_mode(p.mode, n, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, p.si, p.sl, p.last, p.block_n);
+  const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si, p.sl, p.last, p.block_n);
   const int cnt = tr.count();
   const int pieces = imax(1, ceil_div(cnt, p.chunk));
   fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, cnt, p.row_ptr[qb],
@@ -290,9 +296,10 @@ extern "C" int tmx_build_block_index(tmx_index_t* idx, const int32_t* cu_q_dev, 
                     (idx->cap_items == 0 || idx->items) && (idx->cap_split == 0 || idx->split_qb),
                 "tmx_build_block_index: NULL buffer with non-zero capacity");
   TMX_CHECK_ARG((reinterpret_cast<uintptr_t>(idx->items) & 15) == 0, "tmx_build_block_index: items must be 16-byte aligned");
-  if (cu_q_host && seq_lens_host) {
+  // (full_lens without its host mirror: the sizes cannot be recomputed here, the check is skipped)
+  if (cu_q_host && seq_lens_host && (idx->full_lens == nullptr || idx->full_lens_host != nullptr)) {
     tmx_index_sizes_t sz;
-    int rc = tmx_index_sizes(cu_q_host, seq_lens_host, idx->batch, idx->si, idx->sl, idx->last, idx->block_m,
+    int rc = tmx_index_sizes(cu_q_host, seq_lens_host, idx->full_lens ? idx->full_lens_host : nullptr, idx->batch, idx->si, idx->sl, idx->last, idx->block_m,
                              idx->block_n, idx->mode, idx->tri_min_len, idx->chunk_tiles, &sz);
     if (rc != TMX_OK) return rc;
     if (sz.num_qblocks > idx->cap_qblocks || sz.nnz_tiles > idx->cap_nnz || sz.num_items > idx->cap_items ||
@@ -308,6 +315,7 @@ extern "C" int tmx_build_block_index(tmx_index_t* idx, const int32_t* cu_q_dev, 
   tmx::IndexParams p;
   p.cu_q = cu_q_dev;
   p.seq_lens = seq_lens_dev;
+  p.full_lens = idx->full_lens;
   p.row_ptr = idx->row_ptr;
   p.col_idx = idx->col_idx;
   p.qb_meta = idx->qb_meta;

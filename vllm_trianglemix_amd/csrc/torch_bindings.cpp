@@ -46,7 +46,8 @@ int32_t* i32_opt(const std::optional<Tensor>& t) { return t.has_value() ? i32(*t
 void fill_index(tmx_index_t& ix, const std::vector<Tensor>& b, const std::optional<Tensor>& tile_pages,
                 const std::optional<Tensor>& pages_block_table, int64_t page_size, int64_t si, int64_t sl,
                 int64_t last, int64_t block_m, int64_t block_n, int64_t mode, int64_t tri_min_len,
-                int64_t chunk_tiles, int64_t batch) {
+                int64_t chunk_tiles, int64_t batch, const std::optional<Tensor>& full_lens = std::nullopt,
+                const std::optional<Tensor>& full_lens_cpu = std::nullopt) {
   TORCH_CHECK(b.size() == 8, "trianglemix: the index is a list of 8 tensors");
   ix = tmx_index_t{};
   ix.row_ptr = i32(b[0]);
@@ -78,15 +79,18 @@ void fill_index(tmx_index_t& ix, const std::vector<Tensor>& b, const std::option
     ix.pages_block_table_stride = pages_block_table->stride(0);
     ix.pages_page_size = (int32_t)page_size;
   }
+  ix.full_lens = i32_opt(full_lens);
+  ix.full_lens_host = i32_opt(full_lens_cpu);
 }
 
 // Exact buffer sizes from the host copies of the batch: [R, nnz, items, partials, split q-blocks, max tiles].
 std::vector<int64_t> index_sizes(const Tensor& cu_seqlens_q_cpu, const Tensor& seq_lens_cpu, int64_t si, int64_t sl,
                                  int64_t last, int64_t block_m, int64_t block_n, int64_t mode, int64_t tri_min_len,
-                                 int64_t chunk_tiles) {
-  TORCH_CHECK(cu_seqlens_q_cpu.is_cpu() && seq_lens_cpu.is_cpu(), "trianglemix: host tensors expected");
+                                 int64_t chunk_tiles, const std::optional<Tensor>& full_lens_cpu) {
+  TORCH_CHECK(cu_seqlens_q_cpu.is_cpu() && seq_lens_cpu.is_cpu() && (!full_lens_cpu.has_value() || full_lens_cpu->is_cpu()),
+              "trianglemix: host tensors expected");
   tmx_index_sizes_t sz;
-  check(tmx_index_sizes(i32(cu_seqlens_q_cpu), i32(seq_lens_cpu), (int)seq_lens_cpu.numel(), (int)si, (int)sl,
+  check(tmx_index_sizes(i32(cu_seqlens_q_cpu), i32(seq_lens_cpu), i32_opt(full_lens_cpu), (int)seq_lens_cpu.numel(), (int)si, (int)sl,
                         (int)last, (int)block_m, (int)block_n, (int)mode, (int)tri_min_len, (int)chunk_tiles, &sz));
   return {sz.num_qblocks, sz.nnz_tiles, sz.num_items, sz.num_partials, sz.num_split_qblocks, sz.max_tiles_per_qblock};
 }
@@ -95,11 +99,12 @@ void build_block_index(std::vector<Tensor> index, const std::optional<Tensor>& t
                        const Tensor& seq_lens, const Tensor& cu_seqlens_q_cpu, const Tensor& seq_lens_cpu,
                        const std::optional<Tensor>& block_table, int64_t page_size, int64_t si, int64_t sl,
                        int64_t last, int64_t block_m, int64_t block_n, int64_t mode, int64_t tri_min_len,
-                       int64_t chunk_tiles) {
+                       int64_t chunk_tiles, const std::optional<Tensor>& full_lens,
+                       const std::optional<Tensor>& full_lens_cpu) {
   const DeviceGuard guard(cu_seqlens_q.device());
   tmx_index_t ix;
   fill_index(ix, index, tile_pages, block_table, page_size, si, sl, last, block_m, block_n, mode, tri_min_len,
-             chunk_tiles, seq_lens.numel());
+             chunk_tiles, seq_lens.numel(), full_lens, full_lens_cpu);
   check(tmx_build_block_index(&ix, i32(cu_seqlens_q), i32(seq_lens), i32(cu_seqlens_q_cpu), i32(seq_lens_cpu),
                               stream_of(cu_seqlens_q)));
 }
@@ -110,7 +115,7 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
                const std::optional<Tensor>& tile_pages, const std::optional<Tensor>& partial_o,
                const std::optional<Tensor>& partial_ml, const std::optional<Tensor>& bias, double scale, int64_t si,
                int64_t sl, int64_t last, int64_t mode, int64_t tri_min_len, int64_t chunk_tiles, int64_t num_items,
-               int64_t num_partials, int64_t num_split_qblocks) {
+               int64_t num_partials, int64_t num_split_qblocks, const std::optional<Tensor>& full_lens) {
   const DeviceGuard guard(query.device());
   TORCH_CHECK(query.dim() == 3 && out.dim() == 3, "trianglemix: query / out must be [T, H, D]");
   const bool paged = block_table.has_value();
@@ -119,7 +124,7 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
   const int64_t hkv = key_cache.size(paged ? 2 : 1);
   const int64_t block_m = tmx_attention_block_m((int)query.size(1), (int)hkv);
   fill_index(ix, index, tile_pages, block_table, paged ? key_cache.size(1) : 0, si, sl, last, block_m,
-             tmx_attention_block_n(), mode, tri_min_len, chunk_tiles, seq_lens.numel());
+             tmx_attention_block_n(), mode, tri_min_len, chunk_tiles, seq_lens.numel(), full_lens);
   tmx_attention_args_t a{};
   a.struct_size = sizeof(a);
   a.io_dtype = dtype_code(query);
@@ -189,16 +194,18 @@ void reshape_and_cache(const Tensor& key, const Tensor& value, Tensor& key_cache
 
 TORCH_LIBRARY(_trianglemix_C, m) {
   m.def("trianglemix_index_sizes(Tensor cu_seqlens_q_cpu, Tensor seq_lens_cpu, int si, int sl, int last, int block_m, "
-        "int block_n, int mode, int tri_min_len, int chunk_tiles) -> int[]");
+        "int block_n, int mode, int tri_min_len, int chunk_tiles, Tensor? full_lens_cpu=None) -> int[]");
   m.impl("trianglemix_index_sizes", c10::DispatchKey::CPU, &index_sizes);
   m.def("trianglemix_build_block_index(Tensor(a!)[] index, Tensor? tile_pages, Tensor cu_seqlens_q, Tensor seq_lens, "
         "Tensor cu_seqlens_q_cpu, Tensor seq_lens_cpu, Tensor? block_table, int page_size, int si, int sl, int last, "
-        "int block_m, int block_n, int mode, int tri_min_len, int chunk_tiles) -> ()");
+        "int block_m, int block_n, int mode, int tri_min_len, int chunk_tiles, Tensor? full_lens=None, "
+        "Tensor? full_lens_cpu=None) -> ()");
   m.impl("trianglemix_build_block_index", c10::DispatchKey::CUDA, &build_block_index);
   m.def("trianglemix_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, Tensor? block_table, "
         "Tensor cu_seqlens_q, Tensor seq_lens, Tensor? cu_seqlens_k, Tensor[] index, Tensor? tile_pages, "
         "Tensor? partial_o, Tensor? partial_ml, Tensor? bias, float scale, int si, int sl, int last, int mode, "
-        "int tri_min_len, int chunk_tiles, int num_items, int num_partials, int num_split_qblocks) -> ()");
+        "int tri_min_len, int chunk_tiles, int num_items, int num_partials, int num_split_qblocks, "
+        "Tensor? full_lens=None) -> ()");
   m.impl("trianglemix_attention", c10::DispatchKey::CUDA, &attention);
   m.def("trianglemix_reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, "
         "Tensor slot_mapping) -> ()");

@@ -86,15 +86,22 @@ def attention_block_n() -> int:
 
 
 def index_sizes(cu_seqlens_q_cpu, seq_lens_cpu, si: int, sl: int, last: int, block_m: int, block_n: int,
-                mode: int, chunk_tiles: int = DEFAULT_CHUNK_TILES, tri_min_len: int = 0) -> IndexSizes:
-    """Exact buffer sizes of the index, from the host copies of the batch."""
+                mode: int, chunk_tiles: int = DEFAULT_CHUNK_TILES, tri_min_len: int = 0,
+                full_lens_cpu=None) -> IndexSizes:
+    """Exact buffer sizes of the index, from the host copies of the batch.  ``full_lens_cpu`` (optional):
+    the length every sequence will have once its prompt is complete (chunked prefill)."""
     cu = np.ascontiguousarray(np.asarray(cu_seqlens_q_cpu), dtype=np.int32)
     sl_ = np.ascontiguousarray(np.asarray(seq_lens_cpu), dtype=np.int32)
     if cu.ndim != 1 or sl_.ndim != 1 or cu.shape[0] != sl_.shape[0] + 1:
         raise RuntimeError("cu_seqlens_q must have one more entry than seq_lens")
+    fl = None
+    if full_lens_cpu is not None:
+        fl = np.ascontiguousarray(np.asarray(full_lens_cpu), dtype=np.int32)
+        if fl.shape != sl_.shape:
+            raise RuntimeError("full_lens must have one entry per request")
     sz = IndexSizes()
     check(_lib.load().tmx_index_sizes(cu.ctypes.data_as(ctypes.c_void_p), sl_.ctypes.data_as(ctypes.c_void_p),
-                                      int(sl_.shape[0]), si, sl, last, block_m, block_n, mode, tri_min_len,
+                                      None if fl is None else fl.ctypes.data_as(ctypes.c_void_p), int(sl_.shape[0]), si, sl, last, block_m, block_n, mode, tri_min_len,
                                       chunk_tiles,
                                       ctypes.byref(sz)))
     return sz
@@ -124,6 +131,8 @@ class BlockIndex:
     tri_min_len: int = 0
     tile_pages: Optional[torch.Tensor] = None
     block_table: Optional[torch.Tensor] = None  # kept alive: the C struct points at it
+    full_lens: Optional[torch.Tensor] = None    # (device) kept alive likewise
+    full_lens_cpu: Optional[np.ndarray] = None
 
     @property
     def num_qblocks(self) -> int:
@@ -137,11 +146,15 @@ class BlockIndex:
 def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seqlens_q_cpu, seq_lens_cpu,
                       si: int, sl: int, last: int, block_m: int, block_n: int, mode: int,
                       chunk_tiles: int = DEFAULT_CHUNK_TILES, tri_min_len: int = 0,
-                      block_table: Optional[torch.Tensor] = None, page_size: int = 0) -> BlockIndex:
+                      block_table: Optional[torch.Tensor] = None, page_size: int = 0,
+                      full_lens: Optional[torch.Tensor] = None, full_lens_cpu=None) -> BlockIndex:
     """Build the packed block-sparse index on the device (two launches, no
     host synchronisation; buffer sizes come from the host copies).  With a
     ``block_table`` (int32 ``[B, max_blocks]``) and ``page_size`` the physical
-    pages of every listed tile are resolved as well (paged K/V, ``block_n`` 32)."""
+    pages of every listed tile are resolved as well (paged K/V, ``block_n`` 32).
+    ``full_lens`` (int32 ``[B]`` on the device, with its host copy): the length each
+    sequence will have once its prompt is complete, so that the steps of a chunked
+    prefill attend exactly as the one-step prefill of the whole prompt does."""
     _require_gpu(cu_seqlens_q, "cu_seqlens_q")
     _require_gpu(seq_lens, "seq_lens")
     if cu_seqlens_q.dtype != torch.int32 or seq_lens.dtype != torch.int32:
@@ -152,7 +165,15 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
     batch = int(sl_h.shape[0])
     if seq_lens.numel() != batch or cu_seqlens_q.numel() != batch + 1:
         raise RuntimeError("device and host batch descriptions differ in length")
-    sz = index_sizes(cu_h, sl_h, si, sl, last, block_m, block_n, mode, chunk_tiles, tri_min_len)
+    fl_h = None
+    if (full_lens is None) != (full_lens_cpu is None):
+        raise RuntimeError("full_lens and full_lens_cpu go together")
+    if full_lens is not None:
+        _require_gpu(full_lens, "full_lens")
+        fl_h = np.ascontiguousarray(np.asarray(full_lens_cpu), dtype=np.int32)
+        if full_lens.dtype != torch.int32 or full_lens.numel() != batch or fl_h.shape[0] != batch:
+            raise RuntimeError("full_lens must be int32 with one entry per request")
+    sz = index_sizes(cu_h, sl_h, si, sl, last, block_m, block_n, mode, chunk_tiles, tri_min_len, fl_h)
     R, nnz, n_items, n_split = (int(sz.num_qblocks), int(sz.nnz_tiles), int(sz.num_items),
                                 int(sz.num_split_qblocks))
 
@@ -181,6 +202,8 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
         c.pages_block_table_stride, c.pages_page_size = block_table.stride(0), int(page_size)
     else:
         c.tile_pages, c.pages_block_table, c.pages_block_table_stride, c.pages_page_size = None, None, 0, 0
+    c.full_lens = None if full_lens is None else full_lens.data_ptr()
+    c.full_lens_host = None if fl_h is None else fl_h.ctypes.data_as(ctypes.c_void_p)
     with torch.cuda.device(dev):
         check(_lib.load().tmx_build_block_index(ctypes.byref(c), _ptr(cu_seqlens_q), _ptr(seq_lens),
                                                 cu_h.ctypes.data_as(ctypes.c_void_p),
@@ -188,7 +211,7 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
     return BlockIndex(row_ptr[:R + 1], col_idx[:nnz], qb_meta[:2 * R].view(R, 2) if R else qb_meta[:0].view(0, 2),
                       part_ptr[:R + 1], items[:n_items], split_qb[:n_split], totals, scratch, sz, c, batch,
                       block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
-                      None if tile_pages is None else tile_pages[:nnz], block_table)
+                      None if tile_pages is None else tile_pages[:nnz], block_table, full_lens, fl_h)
 
 
 # --------------------------------------------------------------------------- attention
