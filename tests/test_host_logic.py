@@ -118,6 +118,19 @@ def test_chunk_masks_are_blocks_of_the_whole_mask():
         assert orc.triangle_mask(P + 9, si, sl, last, q_len=1, n_full=P).all() or last <= 1  # N - i = 1 < last
 
 
+def test_inference_config_from_env():
+    from vllm_trianglemix_amd.config import TriangleMixInferenceConfig
+    off = TriangleMixInferenceConfig.from_env({})
+    assert not off.enable_trianglemix and off.to_trianglemix_config() is None
+    on = TriangleMixInferenceConfig.from_env({"VLLM_TRIANGLEMIX_ENABLED": "1", "VLLM_TRIANGLEMIX_LAYERS": "12",
+                                              "VLLM_NPU_OPTIMIZATION": "0"})
+    cfg = on.to_trianglemix_config()
+    assert on.enable_trianglemix and not on.use_npu_optimization
+    assert (cfg.num_sink_tokens, cfg.sliding_window_size, cfg.num_last_tokens, cfg.num_triangle_layers) == (4, 32, 64, 12)
+    assert cfg.should_use_triangle(11) and not cfg.should_use_triangle(12)
+    assert not TriangleMixInferenceConfig.from_env({"VLLM_TRIANGLEMIX_ENABLED": "false"}).enable_trianglemix
+
+
 def test_index_sizes_rejects_bad_input():
     with pytest.raises(RuntimeError):
         ops.index_sizes([0, 5, 9], [5], 4, 32, 64, 32, 32, ops.MODES["triangle"])

@@ -93,6 +93,25 @@ class TriangleMixInferenceConfig:
     # MI355X deployments use the same pattern defaults
     for_mi355x = for_qwen3
 
+    @staticmethod
+    def from_env(environ=None) -> "TriangleMixInferenceConfig":
+        """The run-time switches the reference documents but never reads
+        (trianglemix_config.py:106-110): ``VLLM_TRIANGLEMIX_ENABLED`` (0/1),
+        ``VLLM_TRIANGLEMIX_LAYERS`` (number of triangle layers),
+        ``VLLM_NPU_OPTIMIZATION`` (0/1, kept for compatibility).  Unset variables leave the
+        dataclass defaults (TriangleMix off)."""
+        import os
+        env = os.environ if environ is None else environ
+
+        def flag(name: str, default: bool) -> bool:
+            v = env.get(name)
+            return default if v is None else v.strip().lower() not in ("", "0", "false", "no", "off")
+
+        layers = env.get("VLLM_TRIANGLEMIX_LAYERS")
+        return TriangleMixInferenceConfig(enable_trianglemix=flag("VLLM_TRIANGLEMIX_ENABLED", False),
+                                          num_triangle_layers=None if layers in (None, "") else int(layers),
+                                          use_npu_optimization=flag("VLLM_NPU_OPTIMIZATION", True))
+
 
 def create_trianglemix_config_from_hf(hf_config, use_trianglemix: bool = False,
                                       num_triangle_layers: Optional[int] = None) -> Optional[TriangleMixConfig]:
