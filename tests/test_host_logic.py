@@ -127,7 +127,7 @@ def test_inference_config_from_env():
     cfg = on.to_trianglemix_config()
     assert on.enable_trianglemix and not on.use_npu_optimization
     assert (cfg.num_sink_tokens, cfg.sliding_window_size, cfg.num_last_tokens, cfg.num_triangle_layers) == (4, 32, 64, 12)
-    assert cfg.should_use_triangle(11) and not cfg.should_use_triangle(12)
+    assert cfg.uses_triangle(11) and not cfg.uses_triangle(12)
     assert not TriangleMixInferenceConfig.from_env({"VLLM_TRIANGLEMIX_ENABLED": "false"}).enable_trianglemix
 
 
