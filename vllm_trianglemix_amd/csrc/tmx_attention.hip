@@ -765,21 +765,23 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       }
       const float m_new = m_run;
       frag pf[CNT], pl[CNT];
-      float psum = 0.f;
+      f32x2 psum2 = f32x2{0.f, 0.f};  // packed arithmetic: two scores per instruction
+      const f32x2 mult2 = f32x2{mult, mult}, mneg2 = f32x2{-m_new, -m_new};
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
         uint32_t hi[4], lo[4];
 #pragma unroll
         for (int c = 0; c < 8; c += 2) {
-          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][c >> 2][c & 3], mult, -m_new));
-          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][c >> 2][(c & 3) + 1], mult, -m_new));
-          psum += p0 + p1;
+          const f32x2 e = f32x2{s[u][c >> 2][c & 3], s[u][c >> 2][(c & 3) + 1]} * mult2 + mneg2;
+          const float p0 = __builtin_amdgcn_exp2f(e[0]);
+          const float p1 = __builtin_amdgcn_exp2f(e[1]);
+          psum2 += f32x2{p0, p1};
           TR::pack2(p0, p1, hi[c >> 1], lo[c >> 1]);
         }
         pf[u] = __builtin_bit_cast(frag, make_uint4(hi[0], hi[1], hi[2], hi[3]));
         if constexpr (PRECISE) pl[u] = __builtin_bit_cast(frag, make_uint4(lo[0], lo[1], lo[2], lo[3]));
       }
-      l_run += psum;
+      l_run += psum2[0] + psum2[1];
 
       // O^T += V^T P^T (V fragments transposed by the LDS read)
 #pragma unroll
@@ -862,13 +864,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
           uint16_t* po = reinterpret_cast<uint16_t*>(p.out) + orow + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
 #pragma unroll
           for (int c = 0; c < DB / 2; ++c) {
-            s16x4 a, bq;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              a[r] = TR::cvt(acc[2 * c][r] * inv);
-              bq[r] = TR::cvt(acc[2 * c + 1][r] * inv);
-            }
-            const uint2 au = __builtin_bit_cast(uint2, a), bu = __builtin_bit_cast(uint2, bq);
+            // packed conversions: two columns per instruction
+            const f32x4 oa = acc[2 * c] * inv, ob = acc[2 * c + 1] * inv;
+            const uint2 au = make_uint2(TR::cvt2(oa[0], oa[1]), TR::cvt2(oa[2], oa[3]));
+            const uint2 bu = make_uint2(TR::cvt2(ob[0], ob[1]), TR::cvt2(ob[2], ob[3]));
             const auto r0 = __builtin_amdgcn_permlane16_swap(au.x, bu.x, false, false);
             const auto r1 = __builtin_amdgcn_permlane16_swap(au.y, bu.y, false, false);
             // even 16-lane rows: [own block 2c | partner's block 2c]; odd rows: [partner's block 2c+1 | own]
