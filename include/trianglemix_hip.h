@@ -252,6 +252,36 @@ int tmx_reshape_and_cache(const void* key, const void* value, int64_t kv_in_stri
                           int64_t cache_stride_h, const int64_t* slot_mapping_dev, int32_t num_tokens,
                           int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t dtype, void* stream);
 
+/* ------------------------------------------------------------------------
+ * fp8 (e4m3fn, the format vllm/platforms/rocm.py:402-406 selects on gfx950)
+ * K/V cache, kv_cache_dtype "fp8".
+ *
+ * tmx_reshape_and_cache_fp8: the cache write of reshape_and_cache_flash with an
+ * fp8 cache (csrc/cache_kernels.cu:282-355 + the scaled conversion of
+ * csrc/quantization/fp8/amd/quant_utils.cuh): byte = fp8(x / scale), nearest
+ * even, finite values saturate at +-448.  Cache strides in elements (bytes).
+ *
+ * tmx_gather_dequant_kv_fp8: the keys / values a step attends to, converted
+ * back (fp8 * scale, one rounding to the 16-bit type) into contiguous rows
+ * k_out / v_out [cu_seqlens_k[batch], num_kv_heads, head_dim]; request b's key
+ * j is row cu_seqlens_k[b] + j.  tmx_attention then runs in its contiguous
+ * mode on them: the descale step of the reference's attention kernel
+ * (k_descale / v_descale, vllm/v1/attention/backends/rocm_attn.py:421-422),
+ * done ahead of the kernel instead of inside it.
+ * ---------------------------------------------------------------------- */
+int tmx_reshape_and_cache_fp8(const void* key, const void* value, int64_t kv_in_stride_t, int64_t kv_in_stride_h,
+                              void* key_cache, void* value_cache, int64_t cache_stride_page, int64_t cache_stride_t,
+                              int64_t cache_stride_h, const int64_t* slot_mapping_dev, int32_t num_tokens,
+                              int32_t num_kv_heads, int32_t head_dim, int32_t page_size, int32_t in_dtype,
+                              float k_scale, float v_scale, void* stream);
+
+int tmx_gather_dequant_kv_fp8(const void* key_cache, const void* value_cache, int64_t cache_stride_page,
+                              int64_t cache_stride_t, int64_t cache_stride_h, const int32_t* block_table_dev,
+                              int64_t block_table_stride, int32_t page_size, const int32_t* seq_lens_dev,
+                              const int32_t* cu_seqlens_k_dev, int32_t batch, int32_t max_seq_len,
+                              int32_t num_kv_heads, int32_t head_dim, void* k_out, void* v_out, int32_t out_dtype,
+                              float k_scale, float v_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

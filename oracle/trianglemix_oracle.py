@@ -470,6 +470,45 @@ def bf16_bits(x: np.ndarray) -> np.ndarray:
     return (np.ascontiguousarray(bf16_round(x), dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
 
 
+# --------------------------------------------------------------------------
+# fp8 e4m3fn (the K/V cache format of kv_cache_dtype "fp8" on gfx950,
+# vllm/platforms/rocm.py:402-406): 1 sign, 4 exponent (bias 7), 3 mantissa
+# bits, no infinities, 0x7f / 0xff = NaN, largest finite value 448.
+# --------------------------------------------------------------------------
+
+def fp8_e4m3fn_decode(b: np.ndarray) -> np.ndarray:
+    b = np.asarray(b, np.uint8).astype(np.int64)
+    e, m = (b >> 3) & 15, b & 7
+    mag = np.where(e == 0, m / 8.0 * 2.0 ** -6, (1.0 + m / 8.0) * np.exp2((e - 7).astype(np.float64)))
+    mag = np.where((e == 15) & (m == 7), np.nan, mag)
+    return np.where(b >> 7, -mag, mag)
+
+
+_FP8_POS = fp8_e4m3fn_decode(np.arange(127, dtype=np.uint8))  # codes 0 .. 126: 0 .. 448, ascending
+
+
+def fp8_e4m3fn_encode(x: np.ndarray) -> np.ndarray:
+    """Round to nearest, ties to even; finite values saturate at +-448 (the
+    scaled conversion of csrc/quantization/fp8/amd/quant_utils.cuh); NaN -> 0x7f."""
+    x = np.asarray(x, np.float64)
+    ax = np.minimum(np.abs(x), 448.0)
+    hi = np.clip(np.searchsorted(_FP8_POS, ax, side="left"), 0, 126)
+    lo = np.maximum(hi - 1, 0)
+    d_lo, d_hi = ax - _FP8_POS[lo], _FP8_POS[hi] - ax
+    pick_hi = (d_hi < d_lo) | ((d_hi == d_lo) & (hi % 2 == 0))
+    code = np.where(pick_hi, hi, lo).astype(np.uint8)
+    code = np.where(np.isnan(x), np.uint8(0x7F), code)
+    return (code | np.where(np.signbit(x) & ~np.isnan(x), 0x80, 0).astype(np.uint8)).astype(np.uint8)
+
+
+def fp8_cache_roundtrip(x: np.ndarray, scale: float = 1.0) -> np.ndarray:
+    """What the attention sees of a value written to an fp8 cache: fp8(x / scale) * scale (float64;
+    the 16-bit rounding of the descaled value is the caller's, see :func:`bf16_round`)."""
+    inv = np.float32(1.0) / np.float32(scale)  # the write multiplies by the reciprocal, in fp32
+    q = fp8_e4m3fn_encode((np.asarray(x, np.float32) * inv).astype(np.float32))
+    return (fp8_e4m3fn_decode(q).astype(np.float32) * np.float32(scale)).astype(np.float64)
+
+
 def seeded_normal(seed: int, shape) -> np.ndarray:
     """Deterministic N(0,1) float32 inputs (numpy PCG64), rounded to bf16."""
     return bf16_round(np.random.default_rng(seed).standard_normal(shape, dtype=np.float32))

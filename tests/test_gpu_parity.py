@@ -667,6 +667,101 @@ def test_backend_forward_mixed_batch():
     assert len(md._indices) == 2
 
 
+def test_fp8_kv_cache_write_gather_and_backend():
+    """kv_cache_dtype "fp8" (e4m3fn): the cache write is bit-exact against the oracle's conversion
+    (itself pinned to torch's on the CPU), the gather returns fp8 * scale rounded once to bf16, and the
+    backend attends to what the cache holds (oracle on the dequantised keys / values)."""
+    import types
+    from vllm_trianglemix_amd import TriangleMixConfig
+    from vllm_trianglemix_amd.backend import TriangleMixAttentionBackend
+    ops = _ops()
+    H, Hkv, D, page = 8, 2, 128, 16
+    k_scale, v_scale = 0.75, 1.5
+    q_lens, seq_lens = [2200, 40, 1], [2200, 300, 700]
+    q, ks, vs = _rand_case(808, q_lens, seq_lens, H, Hkv, D)
+    ks[0][5, 0, :4] = [1000.0, -1000.0, 336.1, 1e-4]  # saturation at +-448 * scale, a tiny value
+    scale = D ** -0.5
+    cu = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    T = int(cu[-1])
+    nblk = sum((s + page - 1) // page for s in seq_lens) + 2
+    perm = np.random.default_rng(5).permutation(nblk).astype(np.int32)
+    kv_cache = torch.zeros((2, nblk, page, Hkv, D), dtype=torch.uint8, device=DEV)
+    maxb = max((s + page - 1) // page for s in seq_lens)
+    bt = np.zeros((len(seq_lens), maxb), np.int32)
+    nxt = 0
+    # every token goes through the fp8 write: the context in a first call, the step's rows in forward()
+    ctx_rows_k, ctx_rows_v, ctx_slots = [], [], []
+    slots = np.zeros((T,), np.int64)
+    k_new, v_new = np.zeros((T, Hkv, D), np.float32), np.zeros((T, Hkv, D), np.float32)
+    for b, (ql, s) in enumerate(zip(q_lens, seq_lens)):
+        for pb in range((s + page - 1) // page):
+            bt[b, pb] = perm[nxt]
+            nxt += 1
+        ctx = s - ql
+        jj = np.arange(ctx)
+        ctx_rows_k.append(ks[b][:ctx]); ctx_rows_v.append(vs[b][:ctx])
+        ctx_slots.append(bt[b, jj // page].astype(np.int64) * page + jj % page)
+        pos = np.arange(ctx, s)
+        slots[cu[b]:cu[b + 1]] = bt[b, pos // page].astype(np.int64) * page + pos % page
+        k_new[cu[b]:cu[b + 1]], v_new[cu[b]:cu[b + 1]] = ks[b][ctx:], vs[b][ctx:]
+    ck = _to_dev(np.concatenate(ctx_rows_k), torch.bfloat16)
+    cv = _to_dev(np.concatenate(ctx_rows_v), torch.bfloat16)
+    cs = np.concatenate(ctx_slots)
+    cs_pad = np.concatenate([cs, [-1]])  # a padding slot is skipped
+    ops.reshape_and_cache_fp8(torch.cat([ck, ck[:1]]), torch.cat([cv, cv[:1]]), kv_cache[0], kv_cache[1],
+                              torch.from_numpy(cs_pad).to(DEV), k_scale, v_scale)
+    torch.cuda.synchronize()
+    flat_k = kv_cache[0].view(nblk * page, Hkv, D).cpu().numpy()
+    flat_v = kv_cache[1].view(nblk * page, Hkv, D).cpu().numpy()
+    inv_k, inv_v = np.float32(1.0) / np.float32(k_scale), np.float32(1.0) / np.float32(v_scale)
+    want_k = orc.fp8_e4m3fn_encode(ck.float().cpu().numpy() * inv_k)
+    want_v = orc.fp8_e4m3fn_encode(cv.float().cpu().numpy() * inv_v)
+    assert np.array_equal(flat_k[cs], want_k) and np.array_equal(flat_v[cs], want_v)
+    untouched = np.ones(nblk * page, bool)
+    untouched[cs] = False
+    assert not flat_k[untouched].any()
+    # the step through the backend
+    common = types.SimpleNamespace(
+        num_actual_tokens=T, max_query_len=max(q_lens), max_seq_len=max(seq_lens),
+        query_start_loc=torch.from_numpy(cu).to(DEV), query_start_loc_cpu=torch.from_numpy(cu),
+        seq_lens=torch.tensor(seq_lens, dtype=torch.int32, device=DEV),
+        seq_lens_cpu=torch.tensor(seq_lens, dtype=torch.int32),
+        block_table_tensor=torch.from_numpy(bt).to(DEV), slot_mapping=torch.from_numpy(slots).to(DEV))
+    md = TriangleMixAttentionBackend.get_builder_cls()(types.SimpleNamespace(block_size=page), ["l0"], None,
+                                                       torch.device(DEV)).build(0, common)
+    impl = TriangleMixAttentionBackend.get_impl_cls()(H, D, scale, Hkv, None, None, "fp8", None, "decoder", None,
+                                                      trianglemix_config=TriangleMixConfig(num_triangle_layers=1),
+                                                      layer_idx=0)
+    layer = types.SimpleNamespace(_k_scale_float=k_scale, _v_scale_float=v_scale)
+    out = torch.zeros((T, H * D), dtype=torch.bfloat16, device=DEV)
+    impl.forward(layer, _to_dev(q, torch.bfloat16), _to_dev(k_new, torch.bfloat16), _to_dev(v_new, torch.bfloat16),
+                 kv_cache.view(torch.float8_e4m3fn), md, output=out)
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy().reshape(T, H, D)
+    # what the attention sees: bf16(fp8(bf16(x) / scale) * scale)
+    def seen(x, sc):
+        return orc.bf16_round(orc.fp8_cache_roundtrip(orc.bf16_round(x), sc).astype(np.float32))
+    kd = [seen(k, k_scale) for k in ks]
+    vd = [seen(v, v_scale) for v in vs]
+    assert abs(kd[0][5, 0, 0] - 448 * k_scale) < 1e-6 and abs(kd[0][5, 0, 1] + 448 * k_scale) < 1e-6
+    # the gather on its own: bit-exact rows
+    cu_k = np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)
+    k_rows, v_rows = ops.gather_dequant_kv_fp8(kv_cache[0], kv_cache[1], torch.from_numpy(bt).to(DEV),
+                                               torch.tensor(seq_lens, dtype=torch.int32, device=DEV),
+                                               torch.from_numpy(cu_k).to(DEV), int(cu_k[-1]), max(seq_lens),
+                                               torch.bfloat16, k_scale, v_scale)
+    torch.cuda.synchronize()
+    assert np.array_equal(k_rows.float().cpu().numpy(), np.concatenate(kd).astype(np.float32))
+    assert np.array_equal(v_rows.float().cpu().numpy(), np.concatenate(vd).astype(np.float32))
+    ref = np.zeros((T, H, D))
+    for b, (ql, s) in enumerate(zip(q_lens, seq_lens)):
+        mode = "triangle" if s > 2048 else "causal"
+        ref[cu[b]:cu[b + 1]] = orc.varlen_gqa_attention(q[cu[b]:cu[b + 1]], lambda _: kd[b], lambda _: vd[b], [0, ql],
+                                                        [s], scale, mode, 4, 32, 64)
+    err = np.abs(got - ref)
+    assert np.all(err <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8), err.max()
+
+
 def test_torch_library_binding_equals_ctypes_path():
     """torch.ops._trianglemix_C.* (TORCH_LIBRARY registration) drives the same entry points as the
     ctypes binding: identical index, bit-identical attention output."""

@@ -55,7 +55,8 @@ def test_torch_library_binding_registers_ops():
     from vllm_trianglemix_amd import torch_ops
     C = torch_ops.load()
     for name in ("trianglemix_index_sizes", "trianglemix_build_block_index", "trianglemix_attention",
-                 "trianglemix_reshape_and_cache"):
+                 "trianglemix_reshape_and_cache", "trianglemix_reshape_and_cache_fp8",
+                 "trianglemix_gather_dequant_kv_fp8"):
         assert hasattr(C, name)
     cu, sl = torch.tensor([0, 100, 164], dtype=torch.int32), torch.tensor([100, 2500], dtype=torch.int32)
     got = C.trianglemix_index_sizes(cu, sl, 4, 32, 64, 32, 32, ops.MODES["triangle"], 0, 32)
@@ -116,6 +117,25 @@ def test_chunk_masks_are_blocks_of_the_whole_mask():
             assert np.array_equal(orc.triangle_mask(hi, si, sl, last, q_len=hi - lo, n_full=P), whole[lo:hi, :hi])
         # a decode row past the prompt is dense-causal whatever the prompt length was
         assert orc.triangle_mask(P + 9, si, sl, last, q_len=1, n_full=P).all() or last <= 1  # N - i = 1 < last
+
+
+def test_fp8_e4m3fn_oracle_matches_torch():
+    """The oracle's fp8 conversions are pinned to torch's float8_e4m3fn (CPU) on every finite code, on
+    midpoints between neighbouring codes (ties to even) and on random values; beyond +-448 the oracle
+    saturates, as the cache write of the reference does (quant_utils.cuh), where torch gives NaN."""
+    allb = np.arange(256, dtype=np.uint8)
+    want = torch.from_numpy(allb).view(torch.float8_e4m3fn).float().numpy()
+    got = orc.fp8_e4m3fn_decode(allb)
+    assert np.array_equal(np.isnan(want), np.isnan(got)) and np.array_equal(want[~np.isnan(want)], got[~np.isnan(got)])
+    pos = got[:127]
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.normal(size=50000) * rng.choice([1e-3, 0.1, 1, 30, 200], 50000), pos, -pos,
+                        (pos[1:] + pos[:-1]) / 2, [0.0, -0.0, 447.9, 2.0 ** -10, 2.0 ** -9 * 0.5]]).astype(np.float32)
+    x = x[np.abs(x) <= 448]
+    t = torch.from_numpy(x).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    assert np.array_equal(t, orc.fp8_e4m3fn_encode(x))
+    assert orc.fp8_e4m3fn_encode(np.asarray([1e9, -500.0, np.nan])).tolist() == [126, 254, 127]
+    assert orc.fp8_cache_roundtrip(np.asarray([3.0, 1000.0], np.float32), 2.0).tolist() == [3.0, 896.0]
 
 
 def test_inference_config_from_env():
@@ -269,7 +289,7 @@ def test_impl_constructor_rules():
                                     sliding_window_size=8, num_last_tokens=16)
     assert flag.use_triangle and flag.pattern == (2, 8, 16)
     for bad in (dict(alibi_slopes=[0.5]), dict(sliding_window=128), dict(logits_soft_cap=30.0),
-                dict(kv_cache_dtype="fp8"), dict(attn_type="encoder")):
+                dict(kv_cache_dtype="fp8_e5m2"), dict(attn_type="encoder")):
         kw = dict(num_heads=32, head_size=128, scale=0.088, num_kv_heads=8)
         kw.update(bad)
         with pytest.raises(NotImplementedError):

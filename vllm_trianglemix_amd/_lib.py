@@ -20,6 +20,7 @@ TMX_ABI_VERSION = 2
 EXPORTED_SYMBOLS = (
     "tmx_abi_version", "tmx_last_error", "tmx_attention_block_m", "tmx_attention_block_n", "tmx_dense_mask",
     "tmx_replace_neg_inf", "tmx_index_sizes", "tmx_build_block_index", "tmx_attention", "tmx_reshape_and_cache",
+    "tmx_reshape_and_cache_fp8", "tmx_gather_dequant_kv_fp8",
 )
 
 
@@ -97,6 +98,12 @@ def load() -> ctypes.CDLL:
     lib.tmx_reshape_and_cache.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                           c_int64, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p]
+    lib.tmx_reshape_and_cache_fp8.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
+                                              c_int64, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                              c_float, c_float, c_void_p]
+    lib.tmx_gather_dequant_kv_fp8.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32,
+                                              c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                              c_int32, c_float, c_float, c_void_p]
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name)  # AttributeError if a declared symbol is not exported
     if lib.tmx_abi_version() != TMX_ABI_VERSION:

@@ -214,8 +214,10 @@ class TriangleMixAttentionImpl(_ImplBase):
                                       "(the TriangleMix pattern carries its own window)")
         if logits_soft_cap:
             raise NotImplementedError("logits soft cap is not supported by TriangleMixAttentionImpl")
-        if kv_cache_dtype not in ("auto", "bfloat16", "float16", "half"):
-            raise NotImplementedError(f"kv_cache_dtype '{kv_cache_dtype}' is not supported (16-bit caches only)")
+        if kv_cache_dtype not in ("auto", "bfloat16", "float16", "half", "fp8", "fp8_e4m3"):
+            raise NotImplementedError(f"kv_cache_dtype '{kv_cache_dtype}' is not supported "
+                                      "(16-bit caches and fp8 e4m3 are)")
+        self.fp8_cache = kv_cache_dtype.startswith("fp8")
 
         cfg = trianglemix_config
         if cfg is None:
@@ -249,9 +251,11 @@ class TriangleMixAttentionImpl(_ImplBase):
         m = attn_metadata
         n_tok = m.num_actual_tokens
         key_cache, value_cache = kv_cache.unbind(0)
+        q = query.view(-1, self.num_heads, self.head_size)[:n_tok]
+        if self.fp8_cache:
+            return self._forward_fp8_cache(layer, q, key, value, key_cache, value_cache, m, output)
         if self.kv_sharing_target_layer_name is None and key is not None and value is not None:
             ops.reshape_and_cache(key[:n_tok], value[:n_tok], key_cache, value_cache, m.slot_mapping[:n_tok])
-        q = query.view(-1, self.num_heads, self.head_size)[:n_tok]
         out = output.view(-1, self.num_heads, self.head_size)[:n_tok]
         mode = "triangle" if self.use_triangle else "causal"
         pattern = self.pattern if self.use_triangle else (0, 0, 0)
@@ -260,5 +264,30 @@ class TriangleMixAttentionImpl(_ImplBase):
         ws = m.workspace(idx, self.num_heads, self.head_size, q.device)
         ops.attention(q, key_cache, value_cache, out, idx, m.query_start_loc, m.seq_lens, self.scale,
                       block_table=m.block_table, workspace=ws)
+        return output
+
+    def _forward_fp8_cache(self, layer, q, key, value, key_cache, value_cache, m, output):
+        """kv_cache_dtype "fp8" (rocm_attn.py:356-358, 421-422): the step's rows are written as
+        fp8(x / scale); the attention then reads what the cache holds, times the scale.  The query
+        stays 16-bit, as on ROCm in the reference (rocm_attn.py:362-365).  The descale runs ahead of the
+        attention kernel into contiguous 16-bit rows kept for the step."""
+        n_tok = m.num_actual_tokens
+        k_scale = float(getattr(layer, "_k_scale_float", 1.0))
+        v_scale = float(getattr(layer, "_v_scale_float", 1.0))
+        if self.kv_sharing_target_layer_name is None and key is not None and value is not None:
+            ops.reshape_and_cache_fp8(key[:n_tok], value[:n_tok], key_cache, value_cache, m.slot_mapping[:n_tok],
+                                      k_scale, v_scale)
+        cu_k_cpu = np.concatenate([[0], np.cumsum(m.seq_lens_cpu, dtype=np.int64)]).astype(np.int32)
+        cu_k = torch.from_numpy(cu_k_cpu).to(q.device, non_blocking=True)
+        k_rows, v_rows = ops.gather_dequant_kv_fp8(key_cache, value_cache, m.block_table, m.seq_lens, cu_k,
+                                                   int(cu_k_cpu[-1]), int(m.max_seq_len), q.dtype, k_scale, v_scale)
+        out = output.view(-1, self.num_heads, self.head_size)[:n_tok]
+        mode = "triangle" if self.use_triangle else "causal"
+        pattern = self.pattern if self.use_triangle else (0, 0, 0)
+        tri_min_len = self.tri_min_len if self.use_triangle else 0
+        idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len)
+        ws = m.workspace(idx, self.num_heads, self.head_size, q.device)
+        ops.attention(q, k_rows, v_rows, out, idx, m.query_start_loc, m.seq_lens, self.scale, cu_seqlens_k=cu_k,
+                      workspace=ws)
         return output
 

@@ -190,6 +190,39 @@ void reshape_and_cache(const Tensor& key, const Tensor& value, Tensor& key_cache
                               (int32_t)key_cache.size(1), dtype_code(key), stream_of(key)));
 }
 
+// fp8 (e4m3fn) caches arrive as uint8 or float8_e4m3fn tensors; strides of a one-byte type are bytes.
+void* fp8_ptr(const Tensor& t) {
+  TORCH_CHECK(t.element_size() == 1, "trianglemix: an fp8 cache is a one-byte tensor (uint8 / float8_e4m3fn)");
+  return t.data_ptr();
+}
+
+void reshape_and_cache_fp8(const Tensor& key, const Tensor& value, Tensor& key_cache, Tensor& value_cache,
+                           const Tensor& slot_mapping, double k_scale, double v_scale) {
+  const DeviceGuard guard(key.device());
+  TORCH_CHECK(slot_mapping.scalar_type() == at::kLong && slot_mapping.is_contiguous(),
+              "trianglemix: slot_mapping must be contiguous int64");
+  const int64_t n = std::min<int64_t>(slot_mapping.numel(), key.size(0));
+  check(tmx_reshape_and_cache_fp8(key.data_ptr(), value.data_ptr(), key.stride(0), key.stride(1), fp8_ptr(key_cache),
+                                  fp8_ptr(value_cache), key_cache.stride(0), key_cache.stride(1), key_cache.stride(2),
+                                  slot_mapping.data_ptr<int64_t>(), (int32_t)n, (int32_t)key.size(1),
+                                  (int32_t)key.size(2), (int32_t)key_cache.size(1), dtype_code(key), (float)k_scale,
+                                  (float)v_scale, stream_of(key)));
+}
+
+void gather_dequant_kv_fp8(Tensor& k_rows, Tensor& v_rows, const Tensor& key_cache, const Tensor& value_cache,
+                           const Tensor& block_table, const Tensor& seq_lens, const Tensor& cu_seqlens_k,
+                           int64_t max_seq_len, double k_scale, double v_scale) {
+  const DeviceGuard guard(key_cache.device());
+  TORCH_CHECK(k_rows.is_contiguous() && v_rows.is_contiguous() && k_rows.dim() == 3,
+              "trianglemix: k_rows / v_rows must be contiguous [rows, Hkv, D]");
+  check(tmx_gather_dequant_kv_fp8(fp8_ptr(key_cache), fp8_ptr(value_cache), key_cache.stride(0), key_cache.stride(1),
+                                  key_cache.stride(2), i32(block_table), block_table.stride(0),
+                                  (int32_t)key_cache.size(1), i32(seq_lens), i32(cu_seqlens_k),
+                                  (int32_t)seq_lens.numel(), (int32_t)max_seq_len, (int32_t)key_cache.size(2),
+                                  (int32_t)key_cache.size(3), k_rows.data_ptr(), v_rows.data_ptr(), dtype_code(k_rows),
+                                  (float)k_scale, (float)v_scale, stream_of(key_cache)));
+}
+
 }  // namespace
 
 TORCH_LIBRARY(_trianglemix_C, m) {
@@ -210,4 +243,10 @@ TORCH_LIBRARY(_trianglemix_C, m) {
   m.def("trianglemix_reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, "
         "Tensor slot_mapping) -> ()");
   m.impl("trianglemix_reshape_and_cache", c10::DispatchKey::CUDA, &reshape_and_cache);
+  m.def("trianglemix_reshape_and_cache_fp8(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, "
+        "Tensor slot_mapping, float k_scale, float v_scale) -> ()");
+  m.impl("trianglemix_reshape_and_cache_fp8", c10::DispatchKey::CUDA, &reshape_and_cache_fp8);
+  m.def("trianglemix_gather_dequant_kv_fp8(Tensor! k_rows, Tensor! v_rows, Tensor key_cache, Tensor value_cache, "
+        "Tensor block_table, Tensor seq_lens, Tensor cu_seqlens_k, int max_seq_len, float k_scale, float v_scale) -> ()");
+  m.impl("trianglemix_gather_dequant_kv_fp8", c10::DispatchKey::CUDA, &gather_dequant_kv_fp8);
 }

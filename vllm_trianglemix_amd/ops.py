@@ -325,3 +325,66 @@ def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.T
             _ptr(key), _ptr(value), key.stride(0), key.stride(1), _ptr(key_cache), _ptr(value_cache),
             key_cache.stride(0), key_cache.stride(1), key_cache.stride(2), _ptr(slot_mapping), n_tok,
             key.shape[1], key.shape[2], key_cache.shape[1], dtype_code(key.dtype), _stream(key.device)))
+
+
+# --------------------------------------------------------------------------- fp8 K/V cache
+FP8_DTYPE = torch.float8_e4m3fn  # the format vllm/platforms/rocm.py:402-406 selects on gfx950
+
+
+def _as_bytes(cache: torch.Tensor) -> torch.Tensor:
+    if cache.dtype not in (torch.uint8, FP8_DTYPE):
+        raise RuntimeError(f"an fp8 cache is uint8 or {FP8_DTYPE}, not {cache.dtype}")
+    return cache.view(torch.uint8)
+
+
+def reshape_and_cache_fp8(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                          slot_mapping: torch.Tensor, k_scale: float = 1.0, v_scale: float = 1.0) -> None:
+    """Write this step's K/V rows into an fp8 (e4m3fn) paged cache: byte = fp8(x / scale)
+    (reshape_and_cache_flash with kv_cache_dtype "fp8", rocm_attn.py:345-354)."""
+    for t, name in ((key, "key"), (value, "value"), (key_cache, "key_cache"), (value_cache, "value_cache"),
+                    (slot_mapping, "slot_mapping")):
+        _require_gpu(t, name)
+    if slot_mapping.dtype != torch.int64 or not slot_mapping.is_contiguous():
+        raise RuntimeError("slot_mapping must be contiguous int64")
+    if key.shape != value.shape or key.stride() != value.stride() or key.dim() != 3:
+        raise RuntimeError("key and value must be [T, Hkv, D] with equal strides")
+    kc, vc = _as_bytes(key_cache), _as_bytes(value_cache)
+    if kc.shape != vc.shape or kc.stride() != vc.stride() or kc.dim() != 4:
+        raise RuntimeError("caches must be [num_blocks, page_size, Hkv, D] with equal strides")
+    n_tok = min(int(slot_mapping.numel()), key.shape[0])
+    with torch.cuda.device(key.device):
+        check(_lib.load().tmx_reshape_and_cache_fp8(
+            _ptr(key), _ptr(value), key.stride(0), key.stride(1), _ptr(kc), _ptr(vc), kc.stride(0), kc.stride(1),
+            kc.stride(2), _ptr(slot_mapping), n_tok, key.shape[1], key.shape[2], kc.shape[1], dtype_code(key.dtype),
+            float(k_scale), float(v_scale), _stream(key.device)))
+
+
+def gather_dequant_kv_fp8(key_cache: torch.Tensor, value_cache: torch.Tensor, block_table: torch.Tensor,
+                          seq_lens: torch.Tensor, cu_seqlens_k: torch.Tensor, total_rows: int, max_seq_len: int,
+                          out_dtype: torch.dtype, k_scale: float = 1.0, v_scale: float = 1.0,
+                          out: Optional[Sequence[torch.Tensor]] = None):
+    """The keys / values of every request of the step, out of an fp8 cache, as contiguous 16-bit rows
+    ``[total_rows, Hkv, D]`` (request ``b``'s key ``j`` is row ``cu_seqlens_k[b] + j``): the descale of
+    rocm_attn.py:421-422 done ahead of the attention kernel.  Returns ``(k_rows, v_rows)``."""
+    for t, name in ((key_cache, "key_cache"), (value_cache, "value_cache"), (block_table, "block_table"),
+                    (seq_lens, "seq_lens"), (cu_seqlens_k, "cu_seqlens_k")):
+        _require_gpu(t, name)
+    kc, vc = _as_bytes(key_cache), _as_bytes(value_cache)
+    if kc.shape != vc.shape or kc.stride() != vc.stride() or kc.dim() != 4:
+        raise RuntimeError("caches must be [num_blocks, page_size, Hkv, D] with equal strides")
+    if block_table.dtype != torch.int32 or block_table.dim() != 2 or block_table.stride(1) != 1:
+        raise RuntimeError("block_table must be int32 [B, max_blocks] with contiguous rows")
+    hkv, d = kc.shape[2], kc.shape[3]
+    if out is None:
+        k_rows = torch.empty((max(total_rows, 1), hkv, d), dtype=out_dtype, device=kc.device)
+        v_rows = torch.empty_like(k_rows)
+    else:
+        k_rows, v_rows = out
+        if k_rows.shape[0] < total_rows or not k_rows.is_contiguous() or not v_rows.is_contiguous():
+            raise RuntimeError("output rows too small or not contiguous")
+    with torch.cuda.device(kc.device):
+        check(_lib.load().tmx_gather_dequant_kv_fp8(
+            _ptr(kc), _ptr(vc), kc.stride(0), kc.stride(1), kc.stride(2), _ptr(block_table), block_table.stride(0),
+            kc.shape[1], _ptr(seq_lens), _ptr(cu_seqlens_k), int(seq_lens.numel()), int(max_seq_len), hkv, d,
+            _ptr(k_rows), _ptr(v_rows), dtype_code(out_dtype), float(k_scale), float(v_scale), _stream(kc.device)))
+    return k_rows, v_rows
