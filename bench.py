@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--oproj", action="store_true", help="also time o_proj GEMM + all-reduce (reported separately)")
     ap.add_argument("--no-baselines", action="store_true", help="skip the dense and CPU baselines")
     ap.add_argument("--cpu-rows", type=int, default=4096, help="query rows of the CPU-baseline sample")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="rehearsal on one GPU: rank 0's share of an N-GPU job (N prompts, heads / N), no process group")
     ap.add_argument("--cpu-heads", type=int, default=8, help="heads of the CPU-baseline sample")
     return ap.parse_args()
 
@@ -130,9 +132,10 @@ def main():
     from vllm_trianglemix_amd.parallel import RowParallelOutputProjection, shard_heads
 
     n = args.seq_len
-    shard = shard_heads(QWEN3_8B["num_heads"], QWEN3_8B["num_kv_heads"], rank, world)
+    job_world = args.emulate_world if (args.emulate_world > 0 and world == 1) else world
+    shard = shard_heads(QWEN3_8B["num_heads"], QWEN3_8B["num_kv_heads"], rank, job_world)
     H, Hkv, D = shard.num_heads, shard.num_kv_heads, QWEN3_8B["head_dim"]
-    batch = world  # weak scaling: one more prompt per GPU
+    batch = job_world  # weak scaling: one more prompt per GPU
     inp = make_inputs(ops, dev, n, batch, H, Hkv, D, seed=0)  # same prompts on every rank, different head shards
     si, sl, last = PATTERN
     bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
@@ -280,7 +283,8 @@ def main():
             "config": {"workload": f"Qwen3-8B bf16 seq_len={n} TriangleMix prefill (one attention layer: block-index "
                                    f"build + masked attention), sink/window/last={PATTERN}, paged KV page {PAGE}",
                        "global_batch": batch, "seq_len": n, "heads_per_gpu": H, "kv_heads_per_gpu": Hkv,
-                       "head_dim": D, "parallelism": f"tp{world} (heads)" if world > 1 else "single GPU"},
+                       "head_dim": D, "parallelism": f"tp{world} (heads)" if world > 1 else
+                       (f"rank 0 of an emulated tp{job_world} job" if job_world > 1 else "single GPU")},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(line), flush=True)

@@ -102,9 +102,11 @@ int tmx_replace_neg_inf(void* mask_dev, int64_t count, int dtype, float value, v
  *     split_qb[S]      = the q-blocks whose tile list was split, ascending
  * A q-block with more than chunk_tiles tiles is split into pieces of at most
  * chunk_tiles tiles; each piece is one item with its own partial slot, merged
- * by the combine pass of tmx_attention.  Unsplit q-blocks have slot -1.  Items
- * are ordered by q-block DESCENDING (the dense trailing rows start first),
- * pieces of one q-block ascending.
+ * by the combine pass of tmx_attention.  Unsplit q-blocks have slot -1.  The
+ * item list starts with the pieces of all split q-blocks (the long jobs:
+ * q-blocks DESCENDING, pieces of one q-block ascending) and goes on with the
+ * unsplit q-blocks, DESCENDING: the dense trailing rows of every request start
+ * first.
  *
  * Chunked prefill: the reference builds its mask for the whole sequence at
  * once (N = seq_len, trianglemix_attention.py:126-129, 330-332).  When a

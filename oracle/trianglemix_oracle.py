@@ -401,8 +401,10 @@ def block_index_closed_form(q_lens, seq_lens, si, sl, last, bm, bn, mode, full_l
 def work_items(row_ptr: np.ndarray, chunk: int, qb_seq=None, qb_row0=None, q_lens=None, seq_lens=None):
     """Split every q-block's tile list into pieces of at most ``chunk`` tiles.
 
-    Items are listed for q-blocks in DESCENDING order (the heavy trailing
-    rows of a request are launched first), pieces of one q-block ascending.
+    The list starts with the pieces of all split q-blocks (the long jobs:
+    q-blocks DESCENDING, pieces of one q-block ascending) and goes on with
+    the unsplit q-blocks, DESCENDING: whatever the batch, a workgroup that
+    gets a long piece gets it first.
     Each item is ``(qblock, first entry in col_idx, tile count, partial slot)``
     with ``partial slot = -1`` when the q-block has a single piece (the
     attention kernel then writes the final output itself) and otherwise a
@@ -421,7 +423,9 @@ def work_items(row_ptr: np.ndarray, chunk: int, qb_seq=None, qb_row0=None, q_len
     part_ptr = np.zeros(r + 1, np.int64)
     part_ptr[1:] = np.cumsum(nparts)
     items = []
-    for qb in range(r - 1, -1, -1):
+    order = [qb for qb in range(r - 1, -1, -1) if npieces[qb] > 1] + \
+            [qb for qb in range(r - 1, -1, -1) if npieces[qb] <= 1]
+    for qb in order:
         for p in range(int(npieces[qb])):
             start = int(row_ptr[qb]) + p * chunk
             ntile = int(min(chunk, int(row_ptr[qb + 1]) - start))

@@ -77,6 +77,18 @@ struct IndexParams {
   int fused;  // pass 2 inside the scan launch (host: cap_qblocks <= 1024)
 };
 
+// Position of a q-block's first work item.  The list starts with the pieces of all split q-blocks (the
+// long jobs: q-blocks descending, pieces ascending) and goes on with the unsplit q-blocks, descending:
+// whatever the batch, every workgroup that gets a long piece gets it first.
+// total_pieces / total_parts: items and partial slots of the whole index; piece_prefix / part_prefix: of the
+// q-blocks before this one; pieces: its own.
+__device__ __forceinline__ int first_item_of(int total_pieces, int total_parts, int piece_prefix, int part_prefix,
+                                             int pieces) {
+  if (pieces > 1) return total_parts - part_prefix - pieces;
+  const int unsplit_before = piece_prefix - part_prefix;
+  return total_pieces - unsplit_before - 1;  // = total_parts + (unsplit q-blocks after this one)
+}
+
 // Pass 2 for one q-block: entries e0, e0 + estep, ... of its tile list and pieces pc0, pc0 + estep, ...
 __device__ __forceinline__ void fill_qblock(const IndexParams& p, int qb, int b, int r0, int n, int ctx, int q_row0,
                                             const TileRanges& tr, int cnt, int start, int first_item, int slot0,
@@ -94,7 +106,7 @@ __device__ __forceinline__ void fill_qblock(const IndexParams& p, int qb, int b,
         reinterpret_cast<int2*>(p.tile_pages)[start + e] = pg;
       }
     }
-  // work items: q-blocks descending, pieces ascending
+  // work items: pieces of one q-block ascending from first_item
   const int pieces = imax(1, ceil_div(cnt, p.chunk));
   for (int pc = e0; pc < pieces; pc += estep) {
     const int it = first_item + pc;
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
                                           p.sl, p.last, p.block_n);
         is_long = v.x > kLongList;
         if (!is_long)
-          fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, v.x, e.x, run.y - e.y - v.y, e.z, 0, 1);
+          fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, v.x, e.x, first_item_of(run.y, run.z, e.y, e.z, v.y), e.z, 0, 1);
       }
       if (is_long) {
         const int at = atomicAdd(&s_num_long, 1);
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
         const int cnt = tr.count();
         const int pieces = imax(1, ceil_div(cnt, p.chunk));
         fill_qblock(p, lq, lb, lr0, n, ctx, p.cu_q[lb] + lr0, tr, cnt, p.row_ptr[lq],
-                    run.y - p.piece_ptr[lq] - pieces, p.part_ptr[lq], tid, 1024);
+                    first_item_of(run.y, run.z, p.piece_ptr[lq], p.part_ptr[lq], pieces), p.part_ptr[lq], tid, 1024);
       }
       if (num_long > 64) {
         // more long lists than the table holds: the remaining ones are written by their own threads
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
             const int r1 = imin(r0 + p.block_m, ql);
             const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf,
                                               p.si, p.sl, p.last, p.block_n);
-            fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, v.x, e.x, run.y - e.y - v.y, e.z, 0, 1);
+            fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, v.x, e.x, first_item_of(run.y, run.z, e.y, e.z, v.y), e.z, 0, 1);
           }
         }
       }
@@ -274,7 +286,8 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IndexParams p) {
   const int cnt = tr.count();
   const int pieces = imax(1, ceil_div(cnt, p.chunk));
   fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, cnt, p.row_ptr[qb],
-              p.piece_ptr[num_qblocks] - p.piece_ptr[qb] - pieces, p.part_ptr[qb], lane, 64);
+              first_item_of(p.piece_ptr[num_qblocks], p.part_ptr[num_qblocks], p.piece_ptr[qb], p.part_ptr[qb], pieces),
+              p.part_ptr[qb], lane, 64);
 }
 
 }  // namespace tmx
