@@ -28,6 +28,7 @@
 // products, and every lane ends with 8 consecutive output columns per store.
 #include "tmx_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace tmx {
@@ -131,6 +132,7 @@ struct AttnParams {
   int H, Hkv, G, Gw, gw_shift, block_m;  // Gw = 1 << gw_shift query heads per workgroup
   int Y;                      // units per work item: K/V heads x head chunks
   int num_items;
+  int num_heavy, sched_w;     // the first num_heavy items are pieces of split q-blocks; light items per piece (schedule)
   long long units_total;      // work items x Y
   int mode, si, sl, last, tri_min_len;
   int bias_rows, bias_cols, bias_dtype, out_dtype;
@@ -331,8 +333,32 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 
   // ------------------------------------------------------------------ the workgroup's items
   // item fields: a0 = (qb, col_start, ntiles, slot), a1 = (b, q_tok0, pos0, n)
+  // ---- static schedule of this workgroup ("lane" item0 of item_step lanes per K/V head chunk) ----
+  // The list starts with num_heavy pieces of split q-blocks (chunk_tiles tiles each), the light unsplit
+  // q-blocks follow.  Pieces go round the lanes; when they do not divide evenly the lanes that got one piece
+  // fewer take the first sched_e_total light items among themselves (sched_w per lane), and only what is
+  // left goes round all lanes: every lane ends up with about the same amount of work.
+  int sched_h = 0, sched_e = 0, sched_short = 1, sched_p1_base = 0, sched_p2_base = 0;
+  if (item_step > 0) {
+    const int P = imin(p.num_heavy, p.num_items);
+    const int r = P % item_step;
+    int e_total = 0;
+    sched_h = P / item_step + (item0 < r ? 1 : 0);
+    if (r > 0 && p.sched_w > 0) {
+      sched_short = item_step - r;
+      const long long want = (long long)sched_short * p.sched_w;
+      e_total = (int)(want < (long long)(p.num_items - P) ? want : (long long)(p.num_items - P));
+      if (item0 >= r) sched_e = imax(0, (e_total - (item0 - r) + sched_short - 1) / sched_short);
+    }
+    sched_p1_base = P + item0 - r;
+    sched_p2_base = P + e_total + item0 - sched_h * item_step;  // + k * item_step for the k-th item overall
+  }
   auto fetch_item = [&](int k, i32x4& a0, i32x4& a1) -> int {
-    const int item = item0 + k * item_step;  // 32-bit on purpose: compared and indexed on the scalar unit
+    // 32-bit on purpose: compared and indexed on the scalar unit
+    int item;
+    if (k < sched_h) item = item0 + k * item_step;
+    else if (k - sched_h < sched_e) item = sched_p1_base + (k - sched_h) * sched_short;
+    else item = sched_p2_base + (k - sched_e) * item_step;
     const int ok = (item < p.num_items) && (k == 0 || item_step > 0);
     a0 = a1 = i32x4{0, 0, 0, 1};
     if (ok) {
@@ -1024,6 +1050,22 @@ static int launch(const AttnParams& p, bool paged, bool has_bias, int64_t num_sp
   return TMX_OK;
 }
 
+// The schedule's exchange rate: how many light (unsplit) items keep a workgroup busy as long as one piece
+// of a split q-block does.  A piece is chunk_tiles arithmetic-bound tile steps; a light item costs its tile
+// steps plus a fixed part (query rows in, output rows out, set-up) worth about six steps when it runs beside
+// a piece (measured on MI355X: 64-tile pieces against 3-tile items balance at 6..8 items per piece).
+// TMX_SCHED_W overrides it (tuning runs).
+static int sched_light_per_piece(const tmx_attention_args_t* a, const tmx_index_t* ix) {
+  static const char* env = getenv("TMX_SCHED_W");
+  if (env != nullptr) return atoi(env);
+  const long long pieces = a->num_partials, light = a->num_items - a->num_partials;
+  if (pieces <= 0 || light <= 0) return 0;
+  const long long light_tiles = ix->cap_nnz - pieces * ix->chunk_tiles;  // lower bound: last pieces are shorter
+  const double avg = light_tiles > light ? (double)light_tiles / (double)light : 1.0;
+  const double w = (double)ix->chunk_tiles / (6.0 + avg);
+  return w > 64.0 ? 64 : (int)(w + 0.5);
+}
+
 static bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
 }  // namespace tmx
@@ -1150,6 +1192,8 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
 
   p.Y = a->num_kv_heads * (G / p.Gw);
   p.num_items = (int)a->num_items;
+  p.num_heavy = (int)(a->num_partials < a->num_items ? a->num_partials : a->num_items);
+  p.sched_w = sched_light_per_piece(a, ix);
   p.units_total = (long long)a->num_items * p.Y;
   hipStream_t s = (hipStream_t)stream;
   if (a->io_dtype == TMX_BF16) {
