@@ -258,6 +258,38 @@ def main():
         except Exception as e:  # pragma: no cover
             extra["dense_causal_torch_sdpa_error"] = repr(e)[:200]
 
+    if not args.no_baselines and rank == 0 and world == 1:
+        # decode step of the same model (every decode row is a dense last row of the pattern): 64 requests with
+        # 8192 cached tokens each, one query row per request; the kernel streams the K/V of every request once
+        try:
+            Bd, Nd = 64, 8192
+            gd = torch.Generator().manual_seed(1)
+            nblk = Bd * (Nd // PAGE)
+            kcd = torch.randn((nblk, PAGE, Hkv, D), generator=gd).to(dev).bfloat16()
+            vcd = torch.randn((nblk, PAGE, Hkv, D), generator=gd).to(dev).bfloat16()
+            btd = torch.randperm(nblk, generator=gd).to(torch.int32).view(Bd, -1).to(dev)
+            qd = torch.randn((Bd, H, D), generator=gd).to(dev).bfloat16()
+            outd = torch.empty_like(qd)
+            cu_dh, sl_dh = np.arange(Bd + 1, dtype=np.int32), np.full((Bd,), Nd, np.int32)
+            cu_d, sl_d = torch.from_numpy(cu_dh).to(dev), torch.from_numpy(sl_dh).to(dev)
+            idx_d = ops.build_block_index(cu_d, sl_d, cu_dh, sl_dh, si, sl, last, bm, bn, ops.MODES["triangle"],
+                                          chunk_tiles=128, block_table=btd, page_size=PAGE)
+            work_d = ops.alloc_workspace(idx_d, H, D, dev)
+
+            def decode():
+                ops.attention(qd, kcd, vcd, outd, idx_d, cu_d, sl_d, scale, block_table=btd, workspace=work_d)
+
+            for _ in range(5):
+                decode()
+            t_dec = timed(decode, 20)
+            kv_bytes = 2 * Bd * Nd * Hkv * D * 2
+            extra["decode_64x8192_ms"] = t_dec
+            extra["decode_64x8192_kv_GBps"] = kv_bytes / (t_dec * 1e-3) / 1e9
+            extra["decode_64x8192_frac_of_hbm_peak"] = kv_bytes / (t_dec * 1e-3) / 1e9 / HBM_PEAK_GBS
+            del kcd, vcd, work_d
+        except Exception as e:  # pragma: no cover
+            extra["decode_error"] = repr(e)[:200]
+
     if args.oproj:
         hidden = QWEN3_8B["hidden"]
         w = (torch.randn((hidden, H * D), device=dev) * 0.02).bfloat16()
