@@ -8,18 +8,20 @@
 // inside them.
 //
 // Work decomposition
-//   grid.x = work item (q-block piece from the index), grid.y = K/V head x
-//   head chunk.  A workgroup is 4 waves; wave w owns 16 query rows of one
-//   query head: head = group base + (w % heads_per_wg), row block = w / heads_per_wg,
-//   so all waves of a workgroup share the same K/V head and the K/V tiles are
-//   staged once in LDS for all of them.
+//   A persistent grid of (CUs x resident workgroups per CU) workgroups; workgroup b serves the
+//   K/V head chunk b % Y for its whole life and walks a static share of the work list (q-block
+//   pieces from the index; see the schedule inside the kernel).  A workgroup is 8 waves; wave w
+//   owns 16 query rows of one query head: slot = w & 3 picks (head of the K/V group, 32-row
+//   block), w >> 2 the 16-row half, so all waves share the same K/V head and every K/V tile is
+//   staged once in LDS (a ring of 3 tiles filled by LDS-DMA) for all of them.
 //
 // Per 32-key tile and wave (all MFMA are 16x16x32, fp32 accumulate):
 //   S^T[key][row]  = K_tile . Q^T      A = K rows from LDS (ds_read_b128, XOR-swizzled
 //                                      16-byte chunks), B = Q fragments held in registers
 //   online softmax  per lane: the lane's column of S^T is ONE query row
-//                   (row = lane & 15), its 8 values are 8 keys; the row maximum
-//                   needs two cross-lane steps (lanes l, l^16, l^32, l^48)
+//                   (row = lane & 15), its 8 values are 8 keys; a new row maximum
+//                   (rare: the running one is kept within a slack) needs two
+//                   cross-lane steps (lanes l, l^16, l^32, l^48)
 //   O^T[d][row]    += V_tile^T . P^T   A = V columns by ds_read_b64_tr_b16 (hardware
 //                                      transpose), B = P packed to 16 bit in registers
 // Both products sum over an index whose order is free (head dim for S, keys for
