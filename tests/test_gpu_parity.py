@@ -667,6 +667,61 @@ def test_backend_forward_mixed_batch():
     assert len(md._indices) == 2
 
 
+def test_backend_pure_decode_step():
+    """A step of decode rows only (the backend then cuts the contexts into 128-tile pieces): every row is
+    the dense last row of the pattern, contexts from one page to several pieces."""
+    import types
+    from vllm_trianglemix_amd import TriangleMixConfig
+    from vllm_trianglemix_amd.backend import TriangleMixAttentionBackend
+    H, Hkv, D, page = 8, 2, 128, 16
+    seq_lens = [9000, 4100, 1, 17, 2049, 600]
+    q_lens = [1] * len(seq_lens)
+    q, ks, vs = _rand_case(31337, q_lens, seq_lens, H, Hkv, D)
+    scale = D ** -0.5
+    B = len(seq_lens)
+    nblk = sum((s + page - 1) // page for s in seq_lens) + 1
+    perm = np.random.default_rng(9).permutation(nblk).astype(np.int32)
+    kv_cache = torch.zeros(TriangleMixAttentionBackend.get_kv_cache_shape(nblk, page, Hkv, D), dtype=torch.bfloat16,
+                           device=DEV)
+    bt = np.zeros((B, max((s + page - 1) // page for s in seq_lens)), np.int32)
+    slots = np.zeros((B,), np.int64)
+    nxt = 0
+    for b, s in enumerate(seq_lens):
+        for pb in range((s + page - 1) // page):
+            bt[b, pb] = perm[nxt]
+            nxt += 1
+        jj = np.arange(s - 1)  # the context; the last token is this step's
+        if len(jj):
+            blk = torch.from_numpy(bt[b, jj // page].astype(np.int64)).to(DEV)
+            kv_cache[0, blk, torch.from_numpy(jj % page).to(DEV)] = _to_dev(ks[b][:s - 1], torch.bfloat16)
+            kv_cache[1, blk, torch.from_numpy(jj % page).to(DEV)] = _to_dev(vs[b][:s - 1], torch.bfloat16)
+        slots[b] = int(bt[b, (s - 1) // page]) * page + (s - 1) % page
+    cu = np.arange(B + 1, dtype=np.int32)
+    common = types.SimpleNamespace(
+        num_actual_tokens=B, max_query_len=1, max_seq_len=max(seq_lens),
+        query_start_loc=torch.from_numpy(cu).to(DEV), query_start_loc_cpu=torch.from_numpy(cu),
+        seq_lens=torch.tensor(seq_lens, dtype=torch.int32, device=DEV),
+        seq_lens_cpu=torch.tensor(seq_lens, dtype=torch.int32),
+        block_table_tensor=torch.from_numpy(bt).to(DEV), slot_mapping=torch.from_numpy(slots).to(DEV))
+    md = TriangleMixAttentionBackend.get_builder_cls()(types.SimpleNamespace(block_size=page), ["l0"], None,
+                                                       torch.device(DEV)).build(0, common)
+    impl = TriangleMixAttentionBackend.get_impl_cls()(H, D, scale, Hkv, None, None, "auto", None, "decoder", None,
+                                                      trianglemix_config=TriangleMixConfig(num_triangle_layers=1),
+                                                      layer_idx=0)
+    k_new = np.stack([ks[b][-1] for b in range(B)])
+    v_new = np.stack([vs[b][-1] for b in range(B)])
+    out = torch.zeros((B, H * D), dtype=torch.bfloat16, device=DEV)
+    impl.forward(None, _to_dev(q, torch.bfloat16), _to_dev(k_new, torch.bfloat16), _to_dev(v_new, torch.bfloat16),
+                 kv_cache, md, output=out)
+    torch.cuda.synchronize()
+    (idx,) = md._indices.values()
+    assert idx.chunk_tiles == 128 and idx.sizes.num_partials == 3 + 2  # 9000 keys: 3 pieces, 4100 keys: 2
+    got = out.float().cpu().numpy().reshape(B, H, D)
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu, seq_lens, scale, "causal", 0, 0, 0)
+    err = np.abs(got - ref)
+    assert np.all(err <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8), err.max()
+
+
 def test_fp8_kv_cache_write_gather_and_backend():
     """kv_cache_dtype "fp8" (e4m3fn): the cache write is bit-exact against the oracle's conversion
     (itself pinned to torch's on the CPU), the gather returns fp8 * scale rounded once to bf16, and the

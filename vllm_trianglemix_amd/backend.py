@@ -75,9 +75,13 @@ class TriangleMixAttentionMetadata:
         key = (mode, pattern, block_m, tri_min_len)
         idx = self._indices.get(key)
         if idx is None:
+            # a pure decode step streams whole contexts: longer pieces (measured: 128-tile pieces stream
+            # K/V 5-10 % faster than 64-tile ones); steps with prefill rows keep the default
+            chunk = 128 if self.max_query_len <= 1 else ops.DEFAULT_CHUNK_TILES
             idx = ops.build_block_index(self.query_start_loc, self.seq_lens, self.query_start_loc_cpu,
                                         self.seq_lens_cpu, pattern[0], pattern[1], pattern[2], block_m,
-                                        ops.attention_block_n(), ops.MODES[mode], tri_min_len=tri_min_len,
+                                        ops.attention_block_n(), ops.MODES[mode], chunk_tiles=chunk,
+                                        tri_min_len=tri_min_len,
                                         block_table=self.block_table, page_size=self.page_size,
                                         full_lens=self.prompt_lens, full_lens_cpu=self.prompt_lens_cpu)
             self._indices[key] = idx
