@@ -144,9 +144,12 @@ def main():
     kc, vc = inp["kv_cache"][0], inp["kv_cache"][1]
 
     def build(mode):
-        # pages of every listed tile are resolved by the builder (block table lookups leave the attention loop)
+        # pages of every listed tile are resolved by the builder (block table lookups leave the attention loop);
+        # the piece length is the library's advice for this batch (one piece of the dense rows per CU: 64 tiles here)
+        chunk = ops.suggest_chunk_tiles(inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn, ops.MODES[mode],
+                                        ops.units_per_item(H, Hkv)) if mode == "triangle" else CHUNK_TILES
         return ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn,
-                                     ops.MODES[mode], chunk_tiles=CHUNK_TILES, block_table=inp["block_table"],
+                                     ops.MODES[mode], chunk_tiles=chunk, block_table=inp["block_table"],
                                      page_size=PAGE)
 
     idx0 = build("triangle")

@@ -63,6 +63,9 @@ def test_torch_library_binding_registers_ops():
     sz = ops.index_sizes(cu.numpy(), sl.numpy(), 4, 32, 64, 32, 32, ops.MODES["triangle"], chunk_tiles=32)
     assert list(got) == [sz.num_qblocks, sz.nnz_tiles, sz.num_items, sz.num_partials, sz.num_split_qblocks,
                          sz.max_tiles_per_qblock]
+    assert C.trianglemix_suggest_chunk_tiles(torch.tensor([0, 32768], dtype=torch.int32),
+                                             torch.tensor([32768], dtype=torch.int32), 4, 32, 64, 32, 32,
+                                             ops.MODES["triangle"], 0, 8, 256) == 64
     full = torch.tensor([100, 4000], dtype=torch.int32)
     got = C.trianglemix_index_sizes(cu, sl, 4, 32, 64, 32, 32, ops.MODES["triangle"], 0, 32, full)
     sz = ops.index_sizes(cu.numpy(), sl.numpy(), 4, 32, 64, 32, 32, ops.MODES["triangle"], chunk_tiles=32,
@@ -149,6 +152,28 @@ def test_inference_config_from_env():
     assert (cfg.num_sink_tokens, cfg.sliding_window_size, cfg.num_last_tokens, cfg.num_triangle_layers) == (4, 32, 64, 12)
     assert cfg.uses_triangle(11) and not cfg.uses_triangle(12)
     assert not TriangleMixInferenceConfig.from_env({"VLLM_TRIANGLEMIX_ENABLED": "false"}).enable_trianglemix
+
+
+def test_chunk_tiles_advice():
+    """One piece of the dense rows per CU for prompts with sparse and dense rows (the measured optimum on a
+    256-CU MI355X: 16 / 32 / 64 / 128 tiles at 8k / 16k / 32k / 64k tokens for Qwen3-8B's heads), fixed
+    lengths for batches of dense rows only."""
+    u = ops.units_per_item(32, 8)
+    assert u == 8 and ops.units_per_item(16, 8) == 8 and ops.units_per_item(4, 1) == 1 and ops.units_per_item(6, 1) == 3
+    for n, want in ((8192, 16), (16384, 32), (32768, 64), (65536, 128)):
+        assert ops.suggest_chunk_tiles([0, n], [n], 4, 32, 64, 32, 32, ops.MODES["triangle"], u, num_cus=256) == want
+    # a rank's share of an 8-GPU job: 8 prompts, 4 query heads on 1 K/V head
+    assert ops.suggest_chunk_tiles(np.arange(9) * 32768, [32768] * 8, 4, 32, 64, 32, 32, ops.MODES["triangle"], 1,
+                                   num_cus=256) == 64
+    assert ops.suggest_chunk_tiles(np.arange(65), [8192] * 64, 4, 32, 64, 32, 32, ops.MODES["triangle"], u, num_cus=256) == 128
+    assert ops.suggest_chunk_tiles([0, 32768], [32768], 4, 32, 64, 32, 32, ops.MODES["causal"], u, num_cus=256) == 64
+    # chunked prefill: a middle chunk of a long prompt has sparse rows only (no piece to balance): the default
+    assert ops.suggest_chunk_tiles([0, 4096], [8192], 4, 32, 64, 32, 32, ops.MODES["triangle"], u, num_cus=256,
+                                   full_lens_cpu=[32768]) == 64
+    # a wide window: the sparse rows' own lists are never cut (1024-key window = up to 34 tiles per q-block)
+    assert ops.suggest_chunk_tiles([0, 4096], [4096], 4, 1024, 64, 32, 32, ops.MODES["triangle"], u, num_cus=256) == 34
+    with pytest.raises(RuntimeError):
+        ops.suggest_chunk_tiles([0, 9], [5], 4, 32, 64, 32, 32, ops.MODES["triangle"], u, num_cus=256)
 
 
 def test_index_sizes_rejects_bad_input():

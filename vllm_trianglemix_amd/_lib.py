@@ -20,7 +20,7 @@ TMX_ABI_VERSION = 2
 EXPORTED_SYMBOLS = (
     "tmx_abi_version", "tmx_last_error", "tmx_attention_block_m", "tmx_attention_block_n", "tmx_dense_mask",
     "tmx_replace_neg_inf", "tmx_index_sizes", "tmx_build_block_index", "tmx_attention", "tmx_reshape_and_cache",
-    "tmx_reshape_and_cache_fp8", "tmx_gather_dequant_kv_fp8",
+    "tmx_reshape_and_cache_fp8", "tmx_gather_dequant_kv_fp8", "tmx_suggest_chunk_tiles",
 )
 
 
@@ -93,6 +93,8 @@ def load() -> ctypes.CDLL:
     lib.tmx_replace_neg_inf.argtypes = [c_void_p, c_int64, c_int, c_float, c_void_p]
     lib.tmx_index_sizes.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     POINTER(IndexSizes)]
+    lib.tmx_suggest_chunk_tiles.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                            c_int, c_int, c_int, c_int, POINTER(c_int)]
     lib.tmx_build_block_index.argtypes = [POINTER(Index), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.tmx_attention.argtypes = [POINTER(AttentionArgs), c_void_p]
     lib.tmx_reshape_and_cache.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,

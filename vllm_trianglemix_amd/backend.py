@@ -75,9 +75,12 @@ class TriangleMixAttentionMetadata:
         key = (mode, pattern, block_m, tri_min_len)
         idx = self._indices.get(key)
         if idx is None:
-            # a pure decode step streams whole contexts: longer pieces (measured: 128-tile pieces stream
-            # K/V 5-10 % faster than 64-tile ones); steps with prefill rows keep the default
-            chunk = 128 if self.max_query_len <= 1 else ops.DEFAULT_CHUNK_TILES
+            # piece length for this batch and head grouping: one piece of the dense rows per CU when the step
+            # also holds sparse rows, 128-tile pieces for pure decode steps (tmx_suggest_chunk_tiles)
+            chunk = ops.suggest_chunk_tiles(self.query_start_loc_cpu, self.seq_lens_cpu, pattern[0], pattern[1],
+                                            pattern[2], block_m, ops.attention_block_n(), ops.MODES[mode],
+                                            ops.units_per_item(num_heads, num_kv_heads), tri_min_len=tri_min_len,
+                                            full_lens_cpu=self.prompt_lens_cpu)
             idx = ops.build_block_index(self.query_start_loc, self.seq_lens, self.query_start_loc_cpu,
                                         self.seq_lens_cpu, pattern[0], pattern[1], pattern[2], block_m,
                                         ops.attention_block_n(), ops.MODES[mode], chunk_tiles=chunk,

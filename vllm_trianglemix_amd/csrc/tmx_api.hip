@@ -70,4 +70,55 @@ int tmx_index_sizes(const int32_t* cu_q, const int32_t* seq_lens, const int32_t*
   return TMX_OK;
 }
 
+int tmx_suggest_chunk_tiles(const int32_t* cu_q, const int32_t* seq_lens, const int32_t* full_lens, int batch, int si,
+                            int sl, int last, int block_m, int block_n, int mode, int tri_min_len,
+                            int units_per_item, int num_cus, int* out) {
+  TMX_CHECK_ARG(out != nullptr, "tmx_suggest_chunk_tiles: out is NULL");
+  TMX_CHECK_ARG(batch >= 0 && (batch == 0 || (cu_q && seq_lens)), "tmx_suggest_chunk_tiles: NULL batch arrays");
+  TMX_CHECK_ARG(block_m > 0 && block_n > 0 && units_per_item > 0, "tmx_suggest_chunk_tiles: sizes must be positive");
+  if (num_cus <= 0) {
+    int dev = 0;
+    TMX_CHECK_HIP(hipGetDevice(&dev));
+    TMX_CHECK_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  // dense rows (the trailing rows of the pattern, every row of a causal request) against sparse rows
+  long long dense_tiles = 0, sparse_tiles = 0, sparse_blocks = 0;
+  int sparse_max = 0;
+  bool decode_only = true;
+  for (int b = 0; b < batch; ++b) {
+    const int ql = cu_q[b + 1] - cu_q[b];
+    const int n = seq_lens[b];
+    TMX_CHECK_ARG(ql >= 0 && n >= ql, "tmx_suggest_chunk_tiles: request %d has q_len %d, seq_len %d", b, ql, n);
+    if (ql > 1) decode_only = false;
+    const int ctx = n - ql;
+    const int nf = full_lens ? tmx::imax(n, full_lens[b]) : n;
+    const int m = tmx::effective_mode(mode, nf, tri_min_len);
+    for (int r0 = 0; r0 < ql; r0 += block_m) {
+      const int i_max = ctx + tmx::imin(r0 + block_m, ql) - 1;
+      const int cnt = tmx::tile_ranges(m, ctx + r0, i_max, n, nf, si, sl, last, block_n).count();
+      if (m != TMX_MODE_TRIANGLE || (nf - i_max) < last) dense_tiles += cnt;
+      else {
+        sparse_tiles += cnt;
+        ++sparse_blocks;
+        sparse_max = tmx::imax(sparse_max, cnt);
+      }
+    }
+  }
+  int chunk;
+  if (dense_tiles == 0) {
+    chunk = tmx::imax(64, sparse_max);  // nothing to split
+  } else if (sparse_blocks == 0 || sparse_tiles * 4 < dense_tiles) {
+    // (almost) only dense rows: pieces long enough to amortise their partial results, many enough to fill the chip
+    chunk = decode_only ? 128 : 64;
+  } else {
+    // mixed: one piece of the dense rows per CU, so that every CU runs one arithmetic-bound piece beside one
+    // workgroup of memory-bound sparse rows (two workgroups are resident per CU)
+    const long long c = (dense_tiles * units_per_item + num_cus - 1) / num_cus;
+    chunk = (int)(c < 8 ? 8 : (c > 512 ? 512 : c));
+    chunk = tmx::imax(chunk, sparse_max);  // sparse rows stay whole
+  }
+  *out = chunk;
+  return TMX_OK;
+}
+
 }  // extern "C"

@@ -95,6 +95,18 @@ std::vector<int64_t> index_sizes(const Tensor& cu_seqlens_q_cpu, const Tensor& s
   return {sz.num_qblocks, sz.nnz_tiles, sz.num_items, sz.num_partials, sz.num_split_qblocks, sz.max_tiles_per_qblock};
 }
 
+// Piece length advice for a batch and a head grouping (host only).
+int64_t suggest_chunk_tiles(const Tensor& cu_seqlens_q_cpu, const Tensor& seq_lens_cpu, int64_t si, int64_t sl,
+                            int64_t last, int64_t block_m, int64_t block_n, int64_t mode, int64_t tri_min_len,
+                            int64_t units_per_item, int64_t num_cus, const std::optional<Tensor>& full_lens_cpu) {
+  TORCH_CHECK(cu_seqlens_q_cpu.is_cpu() && seq_lens_cpu.is_cpu(), "trianglemix: host tensors expected");
+  int out = 0;
+  check(tmx_suggest_chunk_tiles(i32(cu_seqlens_q_cpu), i32(seq_lens_cpu), i32_opt(full_lens_cpu),
+                                (int)seq_lens_cpu.numel(), (int)si, (int)sl, (int)last, (int)block_m, (int)block_n,
+                                (int)mode, (int)tri_min_len, (int)units_per_item, (int)num_cus, &out));
+  return out;
+}
+
 void build_block_index(std::vector<Tensor> index, const std::optional<Tensor>& tile_pages, const Tensor& cu_seqlens_q,
                        const Tensor& seq_lens, const Tensor& cu_seqlens_q_cpu, const Tensor& seq_lens_cpu,
                        const std::optional<Tensor>& block_table, int64_t page_size, int64_t si, int64_t sl,
@@ -229,6 +241,10 @@ TORCH_LIBRARY(_trianglemix_C, m) {
   m.def("trianglemix_index_sizes(Tensor cu_seqlens_q_cpu, Tensor seq_lens_cpu, int si, int sl, int last, int block_m, "
         "int block_n, int mode, int tri_min_len, int chunk_tiles, Tensor? full_lens_cpu=None) -> int[]");
   m.impl("trianglemix_index_sizes", c10::DispatchKey::CPU, &index_sizes);
+  m.def("trianglemix_suggest_chunk_tiles(Tensor cu_seqlens_q_cpu, Tensor seq_lens_cpu, int si, int sl, int last, "
+        "int block_m, int block_n, int mode, int tri_min_len, int units_per_item, int num_cus, "
+        "Tensor? full_lens_cpu=None) -> int");
+  m.impl("trianglemix_suggest_chunk_tiles", c10::DispatchKey::CPU, &suggest_chunk_tiles);
   m.def("trianglemix_build_block_index(Tensor(a!)[] index, Tensor? tile_pages, Tensor cu_seqlens_q, Tensor seq_lens, "
         "Tensor cu_seqlens_q_cpu, Tensor seq_lens_cpu, Tensor? block_table, int page_size, int si, int sl, int last, "
         "int block_m, int block_n, int mode, int tri_min_len, int chunk_tiles, Tensor? full_lens=None, "

@@ -5,6 +5,7 @@ device memory and the current stream only."""
 from __future__ import annotations
 
 import ctypes
+import math
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -105,6 +106,29 @@ def index_sizes(cu_seqlens_q_cpu, seq_lens_cpu, si: int, sl: int, last: int, blo
                                       chunk_tiles,
                                       ctypes.byref(sz)))
     return sz
+
+
+def units_per_item(num_heads: int, num_kv_heads: int) -> int:
+    """Workgroups that serve one work item: K/V heads x head chunks of a K/V group (4 query heads per
+    workgroup when the group size allows)."""
+    group = num_heads // num_kv_heads
+    return num_kv_heads * (group // math.gcd(group, 4))
+
+
+def suggest_chunk_tiles(cu_seqlens_q_cpu, seq_lens_cpu, si: int, sl: int, last: int, block_m: int, block_n: int,
+                        mode: int, num_units: int, tri_min_len: int = 0, full_lens_cpu=None, num_cus: int = 0) -> int:
+    """``chunk_tiles`` to build the index with (``tmx_suggest_chunk_tiles``): one piece of the dense rows
+    per CU when the batch also holds sparse rows, 64 / 128 (decode) otherwise.  ``num_units`` =
+    :func:`units_per_item`; ``num_cus`` 0 asks the current device."""
+    cu = np.ascontiguousarray(np.asarray(cu_seqlens_q_cpu), dtype=np.int32)
+    sl_ = np.ascontiguousarray(np.asarray(seq_lens_cpu), dtype=np.int32)
+    fl = None if full_lens_cpu is None else np.ascontiguousarray(np.asarray(full_lens_cpu), dtype=np.int32)
+    out = ctypes.c_int(0)
+    check(_lib.load().tmx_suggest_chunk_tiles(cu.ctypes.data_as(ctypes.c_void_p), sl_.ctypes.data_as(ctypes.c_void_p),
+                                              None if fl is None else fl.ctypes.data_as(ctypes.c_void_p),
+                                              int(sl_.shape[0]), si, sl, last, block_m, block_n, mode, tri_min_len,
+                                              int(num_units), int(num_cus), ctypes.byref(out)))
+    return int(out.value)
 
 
 @dataclass
