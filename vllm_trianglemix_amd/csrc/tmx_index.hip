@@ -132,7 +132,13 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
   constexpr int kLongList = 16;  // tile lists longer than this are written by the whole workgroup
   __shared__ Int4 wave_sums[16];
   __shared__ int s_num_qblocks;
-  __shared__ int s_long[64], s_num_long;
+  // q-blocks whose lists the whole workgroup writes: q-block, request, first row, tile / piece / partial prefix
+  __shared__ int s_long[64][6], s_num_long;
+  // up to 1024 requests the batch description is read from memory once and kept here: every later
+  // step looks it up without another trip to memory
+  __shared__ int s_qbp[1025];
+  __shared__ int4 s_req[1024];  // first query row, query rows, keys, full length
+  const bool cached = p.batch <= 1024;
   const int tid = threadIdx.x;
   if (tid == 0) s_num_long = 0;
 
@@ -141,18 +147,35 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
   for (int base = 0; base < p.batch; base += 1024) {
     const int b = base + tid;
     int nqb = 0;
-    if (b < p.batch) nqb = ceil_div(imax(0, p.cu_q[b + 1] - p.cu_q[b]), p.block_m);
+    if (b < p.batch) {
+      const int q0 = p.cu_q[b], q1 = p.cu_q[b + 1];
+      nqb = ceil_div(imax(0, q1 - q0), p.block_m);
+      if (cached) {
+        const int n = p.seq_lens[b];
+        s_req[b] = make_int4(q0, q1 - q0, n, p.full_lens ? imax(n, p.full_lens[b]) : n);
+      }
+    }
     Int4 tot;
     Int4 e = block_exclusive_scan(Int4{nqb, 0, 0, 0}, wave_sums, tot);
-    if (b < p.batch) p.seq_qb_ptr[b] = carry + e.x;
+    if (b < p.batch) {
+      p.seq_qb_ptr[b] = carry + e.x;
+      if (cached) s_qbp[b] = carry + e.x;
+    }
     carry += tot.x;
   }
   if (tid == 0) {
     p.seq_qb_ptr[p.batch] = carry;
+    s_qbp[p.batch <= 1024 ? p.batch : 0] = carry;
     s_num_qblocks = carry;
   }
   __syncthreads();
   const int R = s_num_qblocks;
+  // request b: (first query row, query rows, keys, full length)
+  auto request = [&](int b) -> int4 {
+    if (cached) return s_req[b];
+    const int q0 = p.cu_q[b], n = p.seq_lens[b];
+    return make_int4(q0, p.cu_q[b + 1] - q0, n, p.full_lens ? imax(n, p.full_lens[b]) : n);
+  };
 
   // (b) per q-block counts -> row_ptr / piece_ptr / part_ptr / split positions
   Int4 run{0, 0, 0, 0};
@@ -165,13 +188,12 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
       int lo = 0, hi = p.batch;  // last b with seq_qb_ptr[b] <= qb
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (p.seq_qb_ptr[mid] <= qb) lo = mid; else hi = mid;
+        if ((cached ? s_qbp[mid] : p.seq_qb_ptr[mid]) <= qb) lo = mid; else hi = mid;
       }
       b = lo;
-      r0 = (qb - p.seq_qb_ptr[b]) * p.block_m;
-      const int ql = p.cu_q[b + 1] - p.cu_q[b];
-      const int n = p.seq_lens[b];
-      const int nf = p.full_lens ? imax(n, p.full_lens[b]) : n;
+      r0 = (qb - (cached ? s_qbp[b] : p.seq_qb_ptr[b])) * p.block_m;
+      const int4 rq = request(b);
+      const int ql = rq.y, n = rq.z, nf = rq.w;
       const int ctx = n - ql;
       const int r1 = imin(r0 + p.block_m, ql);
       const int cnt = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si, p.sl, p.last, p.block_n).count();
@@ -195,52 +217,55 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
       // single round: run holds the totals, this thread still holds its q-block's numbers
       bool is_long = false;
       if (qb < R && qb < p.cap_qblocks) {
-        const int ql = p.cu_q[b + 1] - p.cu_q[b];
-        const int n = p.seq_lens[b];
-        const int nf = p.full_lens ? imax(n, p.full_lens[b]) : n;
+        const int4 rq = request(b);
+        const int ql = rq.y, n = rq.z, nf = rq.w;
         const int ctx = n - ql;
         const int r1 = imin(r0 + p.block_m, ql);
         const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si,
                                           p.sl, p.last, p.block_n);
         is_long = v.x > kLongList;
         if (!is_long)
-          fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, v.x, e.x, first_item_of(run.y, run.z, e.y, e.z, v.y), e.z, 0, 1);
+          fill_qblock(p, qb, b, r0, n, ctx, rq.x + r0, tr, v.x, e.x, first_item_of(run.y, run.z, e.y, e.z, v.y), e.z, 0, 1);
       }
       if (is_long) {
         const int at = atomicAdd(&s_num_long, 1);
-        if (at < 64) s_long[at] = qb;
+        if (at < 64) {
+          s_long[at][0] = qb;
+          s_long[at][1] = b;
+          s_long[at][2] = r0;
+          s_long[at][3] = e.x;
+          s_long[at][4] = e.y;
+          s_long[at][5] = e.z;
+        }
       }
       __syncthreads();
       const int num_long = s_num_long;
       for (int k = 0; k < imin(num_long, 64); ++k) {
-        const int lq = s_long[k];
-        const int lb = p.qb_meta[2 * lq], lr0 = p.qb_meta[2 * lq + 1];  // written above by this workgroup
-        const int ql = p.cu_q[lb + 1] - p.cu_q[lb];
-        const int n = p.seq_lens[lb];
-        const int nf = p.full_lens ? imax(n, p.full_lens[lb]) : n;
+        const int lq = s_long[k][0], lb = s_long[k][1], lr0 = s_long[k][2];
+        const int4 rq = request(lb);
+        const int ql = rq.y, n = rq.z, nf = rq.w;
         const int ctx = n - ql;
         const int r1 = imin(lr0 + p.block_m, ql);
         const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + lr0, ctx + r1 - 1, n, nf, p.si,
                                           p.sl, p.last, p.block_n);
         const int cnt = tr.count();
         const int pieces = imax(1, ceil_div(cnt, p.chunk));
-        fill_qblock(p, lq, lb, lr0, n, ctx, p.cu_q[lb] + lr0, tr, cnt, p.row_ptr[lq],
-                    first_item_of(run.y, run.z, p.piece_ptr[lq], p.part_ptr[lq], pieces), p.part_ptr[lq], tid, 1024);
+        fill_qblock(p, lq, lb, lr0, n, ctx, rq.x + lr0, tr, cnt, s_long[k][3],
+                    first_item_of(run.y, run.z, s_long[k][4], s_long[k][5], pieces), s_long[k][5], tid, 1024);
       }
       if (num_long > 64) {
         // more long lists than the table holds: the remaining ones are written by their own threads
         if (is_long) {
           bool listed = false;
-          for (int k = 0; k < 64; ++k) listed = listed || s_long[k] == qb;
+          for (int k = 0; k < 64; ++k) listed = listed || s_long[k][0] == qb;
           if (!listed) {
-            const int ql = p.cu_q[b + 1] - p.cu_q[b];
-            const int n = p.seq_lens[b];
-            const int nf = p.full_lens ? imax(n, p.full_lens[b]) : n;
+            const int4 rq = request(b);
+            const int ql = rq.y, n = rq.z, nf = rq.w;
             const int ctx = n - ql;
             const int r1 = imin(r0 + p.block_m, ql);
             const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf,
                                               p.si, p.sl, p.last, p.block_n);
-            fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, v.x, e.x, first_item_of(run.y, run.z, e.y, e.z, v.y), e.z, 0, 1);
+            fill_qblock(p, qb, b, r0, n, ctx, rq.x + r0, tr, v.x, e.x, first_item_of(run.y, run.z, e.y, e.z, v.y), e.z, 0, 1);
           }
         }
       }
