@@ -280,7 +280,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   constexpr int RPP = 1024 / ROWB;      // rows per 1-KiB LDS-DMA piece (one wave instruction)
   constexpr int PE = ENTRY / 1024;      // pieces per entry
   constexpr int PT = PE / 2;            // ... per tensor of a K/V entry
-  constexpr int PW = PE / kWaves;       // ... fetched by each wave
+  // Waves 0 .. kIssuers-1 fetch the K/V entries (and run the scalar walk that finds them); the others only
+  // meet them at the barrier.  The walk is the same in every wave, so fewer walkers leave more issue slots to
+  // the arithmetic (measured: 4 walkers against 8: dense-causal -10 %, sparse rows -5 %; 2 against 4: no change).
+  constexpr int kIssuers = 4;
+  constexpr int PW = PE / kIssuers;     // ... fetched by each issuing wave
   constexpr bool PRECISE = TR::kSplitP; // P as a sum of two 16-bit terms
   static_assert(PW >= 1 && NS >= 3, "ring too small");
   using frag = typename TR::frag;
@@ -309,11 +313,12 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = 2 * p.kv_stride_t;
 
   // ---- LDS-DMA issue: wave-uniform bases + per-lane constant byte offsets ----
-  // Every wave fetches pieces wave * PW .. + PW - 1 of every K/V entry (one 16-key half of K or
+  // Issuing wave w fetches pieces w * PW .. + PW - 1 of every K/V entry (one 16-key half of K or
   // of V) and all QP pieces of its own Q region.
   const int piece_row = lane / CPR;  // row of this lane inside a 1-KiB piece
   const int piece_cc = lane % CPR;   // its 16-byte chunk
-  const int pi0 = wave * PW;
+  const bool issuer = wave < kIssuers;
+  const int pi0 = (wave % kIssuers) * PW;
   const bool iss_v = pi0 >= PT;
   const int pit0 = pi0 % PT;
   const bool iss_second = pit0 * RPP >= 16;  // keys 16..31 of the tile
@@ -500,8 +505,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   // slots the previous step freed (entries below gs are consumed once every wave is past the barrier).
   auto step_sync = [&](int cnt) {
     TMX_STAMP(ts0);
-    wait_vmcnt_levels<PW>(PW * (gi - gs - cnt) + (gs + cnt - 1 < store_mark ? store_ops : 0) +
-                          (gs + cnt - 1 < q_mark ? q_ops : 0));
+    if (issuer)
+      wait_vmcnt_levels<PW>(PW * (gi - gs - cnt) + (gs + cnt - 1 < store_mark ? store_ops : 0) +
+                            (gs + cnt - 1 < q_mark ? q_ops : 0));
     TMX_STAMP(ts1);
 #ifndef TMX_ABLATE_BARRIER
     // every LDS read of the entries about to be overwritten has returned before the barrier
@@ -509,8 +515,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     __builtin_amdgcn_s_barrier();
 #endif
     TMX_STAMP(ts2);
+    if (issuer) {
 #pragma unroll 1
-    while (i_src != 2 && gi - gs < NS) issue_one();
+      while (i_src != 2 && gi - gs < NS) issue_one();
+    }
     TMX_STAMP(ts3);
     TMX_SEG(0, ts0, ts1);
     TMX_SEG(1, ts1, ts2);
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   };
   // Wait for them: everything this wave issued later (tile pieces, stores) may stay in flight.
   auto wait_q = [&]() {
-    const int n = PW * (gi - q_mark) + q_stores;
+    const int n = (issuer ? PW * (gi - q_mark) : 0) + q_stores;
     if (n >= 12) wait_vmcnt<12>();
     else if (n >= 8) wait_vmcnt<8>();
     else if (n >= 6) wait_vmcnt<6>();
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   if (c_valid) issue_q(ca1);
 #pragma unroll 1
   for (int x = 0; x < NS; ++x)
-    if (i_src != 2) issue_one();
+    if (issuer && i_src != 2) issue_one();
 
   const float mult = HAS_BIAS ? 1.0f : p.scale_log2;  // factor between the accumulated scores and the exponent
 
@@ -918,7 +926,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     cb_valid = fetch_item(ck + 1, cb0, cb1);
     // the cursor follows: what was the next item is the current one now; a cursor that had nothing left
     // (the whole list of the new current item is issued) goes on into the new next item
-    if (i_src == 1) {
+    if (!issuer) {
+    } else if (i_src == 1) {
       i_src = 0;
     } else if (cb_valid) {
       cursor_to(cb0, cb1, 1);
