@@ -128,7 +128,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from vllm_trianglemix_amd import ops
-    from vllm_trianglemix_amd._lib import TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SKIP_COMBINE
+    from vllm_trianglemix_amd._lib import TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES, TMX_ATTN_SKIP_COMBINE
     from vllm_trianglemix_amd.parallel import RowParallelOutputProjection, shard_heads
 
     n = args.seq_len
@@ -280,7 +280,8 @@ def main():
             work_d = ops.alloc_workspace(idx_d, H, D, dev)
 
             def decode():
-                ops.attention(qd, kcd, vcd, outd, idx_d, cu_d, sl_d, scale, block_table=btd, workspace=work_d)
+                ops.attention(qd, kcd, vcd, outd, idx_d, cu_d, sl_d, scale, block_table=btd, workspace=work_d,
+                              flags=TMX_ATTN_SHORT_QUERIES)
 
             for _ in range(5):
                 decode()

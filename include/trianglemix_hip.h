@@ -244,12 +244,16 @@ typedef struct tmx_attention_args_t {
   /* Measurement aids (0 in normal use): TMX_ATTN_SKIP_COMBINE leaves split
    * q-blocks as partials, TMX_ATTN_ONLY_COMBINE runs the merge pass alone, so
    * that each kernel can be timed on its own with stream events. */
+  /* TMX_ATTN_SHORT_QUERIES is a hint, results do not depend on it: no request of the step has more
+   * than 16 query rows (decode, speculative decode); the kernel then lets the waves without rows
+   * fetch the K/V tiles. */
   uint32_t flags;
   uint32_t reserved;
 } tmx_attention_args_t;
 
 #define TMX_ATTN_SKIP_COMBINE 1u
 #define TMX_ATTN_ONLY_COMBINE 2u
+#define TMX_ATTN_SHORT_QUERIES 4u
 
 int tmx_attention(const tmx_attention_args_t* args, void* stream);
 

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import trianglemix_oracle as orc
+from vllm_trianglemix_amd._lib import TMX_ATTN_SHORT_QUERIES
 
 pytestmark = pytest.mark.gpu
 
@@ -230,7 +231,7 @@ def _to_dev(x, dtype):
 
 def _run_varlen(ops, q, k_list, v_list, q_lens, seq_lens, scale, mode, pattern, dtype=torch.bfloat16,
                 out_dtype=torch.float32, paged=False, page_size=16, bias=None, chunk=64, gate=0, q_pad=0,
-                resolve_pages=True, full_lens=None):
+                resolve_pages=True, full_lens=None, flags=0):
     """q: [T, H, D] float32 (already rounded); k_list/v_list: per-request [seq_len, Hkv, D]."""
     T, H, D = q.shape
     Hkv = k_list[0].shape[1]
@@ -279,12 +280,12 @@ def _run_varlen(ops, q, k_list, v_list, q_lens, seq_lens, scale, mode, pattern, 
                     t0 = int(col[e]) * 32
                     assert tp[e, 0] == bt[b_, t0 // page_size]
                     assert tp[e, 1] == bt[b_, min(t0 + 16, seq_lens[b_] - 1) // page_size]
-        ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, bias=bias)
+        ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, bias=bias, flags=flags)
     else:
         kd = _to_dev(np.concatenate(k_list, 0), dtype)
         vd = _to_dev(np.concatenate(v_list, 0), dtype)
         cu_k = torch.from_numpy(np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)).to(DEV)
-        ops.attention(qd, kd, vd, out, idx, cu, sld, scale, cu_seqlens_k=cu_k, bias=bias)
+        ops.attention(qd, kd, vd, out, idx, cu, sld, scale, cu_seqlens_k=cu_k, bias=bias, flags=flags)
     torch.cuda.synchronize()
     return out.float().cpu().numpy()
 
@@ -414,10 +415,13 @@ def test_attention_decode_heavy_batch():
                     ref_g[cu[b]:cu[b + 1]] = orc.varlen_gqa_attention(q[cu[b]:cu[b + 1]], lambda _: ks[b], lambda _: vs[b],
                                                                       [0, ql], [n], scale, "causal", 0, 0, 0)
         want = ref_g if gate else ref
-        got = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, "triangle", (4, 32, 64), paged=True, page_size=16,
-                          chunk=chunk, gate=gate)
-        assert not np.isnan(got).any()
-        assert np.abs(got - want).max() <= ATOL_F32_OUT, (chunk, gate, np.abs(got - want).max())
+        # the short-queries hint only moves the K/V fetch to other waves: same results with and without it,
+        # also on this batch, which does not qualify for it
+        for flags in (0, TMX_ATTN_SHORT_QUERIES):
+            got = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, "triangle", (4, 32, 64), paged=True,
+                              page_size=16, chunk=chunk, gate=gate, flags=flags)
+            assert not np.isnan(got).any()
+            assert np.abs(got - want).max() <= ATOL_F32_OUT, (chunk, gate, flags, np.abs(got - want).max())
 
 
 def test_attention_split_and_combine_long():

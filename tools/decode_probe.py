@@ -5,6 +5,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_trianglemix_amd import ops
+from vllm_trianglemix_amd._lib import TMX_ATTN_SHORT_QUERIES
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
@@ -27,11 +28,11 @@ for chunk in chunks:
                                 block_table=bt, page_size=page)
     ws = ops.alloc_workspace(idx, H, D, dev)
     for _ in range(3):
-        ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=ws)
+        ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=ws, flags=TMX_ATTN_SHORT_QUERIES)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
     for a, b in evs:
         a.record()
-        ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=ws)
+        ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=ws, flags=TMX_ATTN_SHORT_QUERIES)
         b.record()
     torch.cuda.synchronize()
     t = np.median([a.elapsed_time(b) for a, b in evs])

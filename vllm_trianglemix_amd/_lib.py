@@ -68,7 +68,7 @@ class AttentionArgs(Structure):
         ("flags", c_uint32), ("reserved", c_uint32),
     ]
 
-TMX_ATTN_SKIP_COMBINE, TMX_ATTN_ONLY_COMBINE = 1, 2
+TMX_ATTN_SKIP_COMBINE, TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES = 1, 2, 4
 
 
 _lib = None

@@ -99,6 +99,12 @@ class TriangleMixAttentionMetadata:
         return ws
 
 
+def _step_flags(m: "TriangleMixAttentionMetadata") -> int:
+    """Hints for the attention kernel: a step whose requests all have at most 16 query rows (decode)."""
+    from ._lib import TMX_ATTN_SHORT_QUERIES
+    return TMX_ATTN_SHORT_QUERIES if m.max_query_len <= 16 else 0
+
+
 class TriangleMixMetadataBuilder:
     """``AttentionMetadataBuilder`` counterpart (utils.py:232-341; rocm_attn.py:60-135)."""
     cudagraph_support: ClassVar[str] = "NEVER"   # the index depends on the batch: rebuilt every step
@@ -270,7 +276,7 @@ class TriangleMixAttentionImpl(_ImplBase):
         idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len)
         ws = m.workspace(idx, self.num_heads, self.head_size, q.device)
         ops.attention(q, key_cache, value_cache, out, idx, m.query_start_loc, m.seq_lens, self.scale,
-                      block_table=m.block_table, workspace=ws)
+                      block_table=m.block_table, workspace=ws, flags=_step_flags(m))
         return output
 
     def _forward_fp8_cache(self, layer, q, key, value, key_cache, value_cache, m, output):
@@ -295,6 +301,6 @@ class TriangleMixAttentionImpl(_ImplBase):
         idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len)
         ws = m.workspace(idx, self.num_heads, self.head_size, q.device)
         ops.attention(q, k_rows, v_rows, out, idx, m.query_start_loc, m.seq_lens, self.scale, cu_seqlens_k=cu_k,
-                      workspace=ws)
+                      workspace=ws, flags=_step_flags(m))
         return output
 
