@@ -512,14 +512,24 @@ def test_attention_bias_and_fully_masked_rows():
     assert np.abs(got2 - ref2).max() <= ATOL_F32_OUT
 
 
-@pytest.mark.parametrize("n,paged", [(8192, False), (32768, True)])
-def test_attention_properties_at_full_size(n, paged):
-    """Size-independent properties at the BASELINE sizes (Qwen3-8B heads; N = 8192 contiguous K/V,
-    N = 32768 with the paged cache and shuffled block table of the benchmark): the output is linear
-    in V, a constant V returns that constant, and sampled rows (first rows, a middle row, rows
-    around the start of the dense trailing region, the last row) equal the oracle."""
+@pytest.mark.parametrize("n,paged,H,Hkv,cache", [
+    (8192, False, 32, 8, "bf16"),   # Qwen3-8B, 8k prompt
+    (32768, True, 32, 8, "bf16"),   # Qwen3-8B, 32k prompt (the benchmark's workload)
+    (32768, True, 16, 2, "bf16"),   # Qwen3-32B, one of 4 head shards
+    (65536, True, 8, 1, "fp8"),     # 64-head / 8-kv-head model, one of 8 head shards, fp8 cache
+])
+def test_attention_properties_at_full_size(n, paged, H, Hkv, cache):
+    """Size-independent properties at the BASELINE sizes and head shards (N = 8192 contiguous K/V; the
+    others with the paged cache and shuffled block table of the benchmark; the 64k case through the fp8
+    cache: quantising write, gather + descale, attention over the rows): the output is linear in V, a
+    constant V returns that constant, and sampled rows (first rows, a middle row, rows around the start
+    of the dense trailing region, the last row) equal the oracle.  With the fp8 cache linearity in V is
+    checked through the descale factor (doubling v_scale doubles the output exactly) and the oracle
+    attends to the rows the gather returned, which are themselves checked against the oracle's fp8
+    conversion on sampled rows."""
     ops = _ops()
-    H, Hkv, D, page = 32, 8, 128, 16
+    D, page, G = 128, 16, H // Hkv
+    fp8 = cache == "fp8"
     g = torch.Generator(device="cpu").manual_seed(0)
     q = torch.randn((n, H, D), generator=g).to(DEV).bfloat16()
     k = torch.randn((n, Hkv, D), generator=g).to(DEV).bfloat16()
@@ -534,36 +544,64 @@ def test_attention_properties_at_full_size(n, paged):
         bt = perm.view(1, -1).to(DEV)
         pos = torch.arange(n)
         slots = (perm.long()[pos // page] * page + pos % page).to(DEV)
+    in_kernel_pages = paged and not fp8
     idx = ops.build_block_index(cu, sld, cu_h, sl_h, 4, 32, 64, ops.attention_block_m(H, Hkv), 32, 2, chunk_tiles=32,
-                                block_table=bt, page_size=page if paged else 0)
+                                block_table=bt if in_kernel_pages else None, page_size=page if in_kernel_pages else 0)
     outs = []
-    for v in (v1, v2, (v1.float() + v2.float()).bfloat16(), torch.ones_like(v1)):
+    seen_k = seen_v = None
+    if fp8:
+        k_scale, v_scale = 0.75, 1.5
+        kc = torch.zeros((n // page, page, Hkv, D), dtype=torch.uint8, device=DEV)
+        vc = torch.zeros_like(kc)
+        ops.reshape_and_cache_fp8(k, v1, kc, vc, slots, k_scale, v_scale)
+        for vs_ in (v_scale, 2 * v_scale):
+            k_rows, v_rows = ops.gather_dequant_kv_fp8(kc, vc, bt, sld, cu, n, n, torch.bfloat16, k_scale, vs_)
+            o = torch.empty((n, H, D), dtype=torch.float32, device=DEV)
+            ops.attention(q, k_rows, v_rows, o, idx, cu, sld, D ** -0.5, cu_seqlens_k=cu)
+            outs.append(o)
+            if seen_k is None:
+                seen_k, seen_v = k_rows, v_rows
+        assert torch.equal(outs[1], 2 * outs[0])
+        ops.reshape_and_cache_fp8(k, torch.ones_like(v1), kc, vc, slots, k_scale, 1.0)
+        k_rows, v_rows = ops.gather_dequant_kv_fp8(kc, vc, bt, sld, cu, n, n, torch.bfloat16, k_scale, 1.0)
         o = torch.empty((n, H, D), dtype=torch.float32, device=DEV)
-        if paged:
-            kc = torch.zeros((n // page, page, Hkv, D), dtype=torch.bfloat16, device=DEV)
-            vc = torch.zeros_like(kc)
-            ops.reshape_and_cache(k, v, kc, vc, slots)
-            ops.attention(q, kc, vc, o, idx, cu, sld, D ** -0.5, block_table=bt)
-        else:
-            ops.attention(q, k, v, o, idx, cu, sld, D ** -0.5, cu_seqlens_k=cu)
-        outs.append(o)
-    lin = (outs[0] + outs[1] - outs[2]).abs().max().item()
-    assert lin < 0.05  # v1 + v2 is re-rounded to bf16: 2^-8 relative on values up to ~8
-    assert (outs[3] - 1.0).abs().max().item() < 1e-5
+        ops.attention(q, k_rows, v_rows, o, idx, cu, sld, D ** -0.5, cu_seqlens_k=cu)
+        assert (o - 1.0).abs().max().item() < 1e-5
+        # the rows the attention saw are the oracle's conversion of the written rows
+        for r in (0, 1, n // 3, n - 1):
+            want = orc.bf16_round(orc.fp8_cache_roundtrip(k[r].float().cpu().numpy(), k_scale).astype(np.float32))
+            assert np.array_equal(seen_k[r].float().cpu().numpy(), want)
+            want = orc.bf16_round(orc.fp8_cache_roundtrip(v1[r].float().cpu().numpy(), v_scale).astype(np.float32))
+            assert np.array_equal(seen_v[r].float().cpu().numpy(), want)
+    else:
+        for v in (v1, v2, (v1.float() + v2.float()).bfloat16(), torch.ones_like(v1)):
+            o = torch.empty((n, H, D), dtype=torch.float32, device=DEV)
+            if paged:
+                kc = torch.zeros((n // page, page, Hkv, D), dtype=torch.bfloat16, device=DEV)
+                vc = torch.zeros_like(kc)
+                ops.reshape_and_cache(k, v, kc, vc, slots)
+                ops.attention(q, kc, vc, o, idx, cu, sld, D ** -0.5, block_table=bt)
+            else:
+                ops.attention(q, k, v, o, idx, cu, sld, D ** -0.5, cu_seqlens_k=cu)
+            outs.append(o)
+        lin = (outs[0] + outs[1] - outs[2]).abs().max().item()
+        assert lin < 0.05  # v1 + v2 is re-rounded to bf16: 2^-8 relative on values up to ~8
+        assert (outs[3] - 1.0).abs().max().item() < 1e-5
+        seen_k, seen_v = k, v1
     assert not torch.isnan(outs[0]).any()
     rows = [0, 5, 40, n // 2 + 17, n - 1 - 70, n - 64, n - 63, n - 10, n - 1]
-    qn, kn, vn = q.float().cpu().numpy(), k.float().cpu().numpy(), v1.float().cpu().numpy()
+    qn, kn, vn = q.float().cpu().numpy(), seen_k.float().cpu().numpy(), seen_v.float().cpu().numpy()
     got = outs[0].cpu().numpy()
     for i in rows:
         allow = np.zeros((n,), bool)
         for lo, hi in orc.row_intervals(i, n, 4, 32, 64):
             allow[lo:hi + 1] = True
-        for h in (0, 13, 31):
-            s = (kn[:, h // 4, :].astype(np.float64) @ qn[i, h].astype(np.float64)) * D ** -0.5
+        for h in (0, (13 * H) // 32, H - 1):
+            s = (kn[:, h // G, :].astype(np.float64) @ qn[i, h].astype(np.float64)) * D ** -0.5
             s[~allow] = -np.inf
             pr = np.exp(s - s.max())
             pr /= pr.sum()
-            assert np.abs(pr @ vn[:, h // 4, :].astype(np.float64) - got[i, h]).max() <= ATOL_F32_OUT, (i, h)
+            assert np.abs(pr @ vn[:, h // G, :].astype(np.float64) - got[i, h]).max() <= ATOL_F32_OUT, (i, h)
 
 
 def test_reshape_and_cache_and_errors():
