@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (no sparsity)
 QWEN3_8B = dict(num_heads=32, num_kv_heads=8, head_dim=128, hidden=4096)
 PATTERN = (4, 32, 64)  # sink, window, last: the reference defaults
 PAGE = 16
@@ -72,6 +73,16 @@ def make_inputs(ops, dev, n, batch, heads, kv_heads, dim, seed):
     sl_h = np.full((batch,), n, np.int32)
     return dict(q=q, k=k, v=v, kv_cache=kv_cache, block_table=block_table.to(dev), cu_h=cu_h, sl_h=sl_h,
                 cu=torch.from_numpy(cu_h).to(dev), sl=torch.from_numpy(sl_h).to(dev))
+
+
+def allowed_pairs(n, si, sl, last, triangle):
+    """Number of (query, key) pairs the pattern keeps for one n-token prompt (closed form of the row counts)."""
+    i = np.arange(n, dtype=np.int64)
+    causal = i + 1
+    if not triangle:
+        return int(causal.sum())
+    sparse = np.minimum(causal, (si + 1) + (sl + 1))  # sink columns + window; they overlap only while i - sl <= si + 1
+    return int(np.where(n - i < last, causal, sparse).sum())
 
 
 def cpu_baseline(n, heads, dim, rows, sample_heads):
@@ -241,6 +252,14 @@ def main():
             dense_own()
             t_dense = timed(dense_own, 3)
             extra["dense_causal_own_kernel_tokens_per_s"] = batch * n / (t_dense * 1e-3)
+            # matrix-core side: algorithmic flops = 4 * D * heads * kept (query, key) pairs (QK^T and PV, 2 flops each)
+            fl_dense = 4.0 * D * H * batch * allowed_pairs(n, si, sl, last, False)
+            fl_tri = 4.0 * D * H * batch * allowed_pairs(n, si, sl, last, True)
+            extra["mfma"] = {"peak_TFLOPs": MFMA_PEAK_TFLOPS,
+                             "dense_causal_TFLOPs": fl_dense / (t_dense * 1e-3) / 1e12,
+                             "dense_causal_frac_of_peak": fl_dense / (t_dense * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                             "triangle_TFLOPs": fl_tri / (t_attn_ms * 1e-3) / 1e12,
+                             "triangle_frac_of_peak": fl_tri / (t_attn_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS}
             extra["speedup_vs_own_dense"] = t_dense / (ms_per_step)
             del work_c
         except Exception as e:  # pragma: no cover

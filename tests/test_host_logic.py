@@ -366,3 +366,16 @@ def test_shard_heads_rule():
         shard_heads(30, 8, 0, 4)
     with pytest.raises(ValueError):
         shard_heads(32, 8, 0, 3)
+
+
+def test_bench_flop_count_equals_mask_population():
+    """bench.py prices the matrix-core side with the number of kept (query, key) pairs: its closed form
+    equals the population of the oracle's masks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tmx_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for n, (si, sl, last) in ((1, (4, 32, 64)), (70, (4, 32, 64)), (300, (4, 32, 64)), (50, (0, 0, 0)),
+                              (200, (3, 6, 8)), (129, (2, 4, 6))):
+        assert bench.allowed_pairs(n, si, sl, last, True) == int(orc.triangle_mask(n, si, sl, last).sum())
+        assert bench.allowed_pairs(n, si, sl, last, False) == n * (n + 1) // 2
