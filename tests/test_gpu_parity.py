@@ -709,6 +709,71 @@ def test_backend_forward_mixed_batch():
     assert len(md._indices) == 2
 
 
+def test_backend_whole_prompt_step_reads_rows_beside_cache_write(monkeypatch):
+    """A step of whole prompts (no request has context in the cache): the backend attends to the step's own
+    K/V rows while the cache write runs on a second stream.  Same output, bit for bit, as with the write first
+    and the attention over the paged cache; the cache holds the rows afterwards; K/V come as strided slices of
+    one fused projection output, as the model passes them."""
+    import types
+    from vllm_trianglemix_amd import TriangleMixConfig
+    from vllm_trianglemix_amd import backend as be
+    H, Hkv, D, page = 8, 2, 128, 16
+    q_lens = seq_lens = [2300, 100, 33]
+    q, ks, vs = _rand_case(2024, q_lens, seq_lens, H, Hkv, D)
+    scale = D ** -0.5
+    cu = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    T = int(cu[-1])
+    nblk = sum((s + page - 1) // page for s in seq_lens) + 3
+    perm = np.random.default_rng(11).permutation(nblk).astype(np.int32)
+    bt = np.zeros((len(seq_lens), max((s + page - 1) // page for s in seq_lens)), np.int32)
+    slots = np.zeros((T,), np.int64)
+    nxt = 0
+    for b, s in enumerate(seq_lens):
+        for pb in range((s + page - 1) // page):
+            bt[b, pb] = perm[nxt]
+            nxt += 1
+        pos = np.arange(s)
+        slots[cu[b]:cu[b + 1]] = bt[b, pos // page].astype(np.int64) * page + pos % page
+    qkv = torch.zeros((T, (H + 2 * Hkv) * D), dtype=torch.bfloat16, device=DEV)
+    qkv[:, :H * D] = _to_dev(q, torch.bfloat16).view(T, H * D)
+    qkv[:, H * D:(H + Hkv) * D] = _to_dev(np.concatenate(ks), torch.bfloat16).view(T, Hkv * D)
+    qkv[:, (H + Hkv) * D:] = _to_dev(np.concatenate(vs), torch.bfloat16).view(T, Hkv * D)
+    qd, kd, vd = qkv.split([H * D, Hkv * D, Hkv * D], dim=-1)
+    qd, kd, vd = qd.view(T, H, D), kd.view(T, Hkv, D), vd.view(T, Hkv, D)
+    results = []
+    for overlap in (True, False):
+        monkeypatch.setattr(be, "_CACHE_WRITE_STREAM", overlap)
+        common = types.SimpleNamespace(
+            num_actual_tokens=T, max_query_len=max(q_lens), max_seq_len=max(seq_lens),
+            query_start_loc=torch.from_numpy(cu).to(DEV), query_start_loc_cpu=torch.from_numpy(cu),
+            seq_lens=torch.tensor(seq_lens, dtype=torch.int32, device=DEV),
+            seq_lens_cpu=torch.tensor(seq_lens, dtype=torch.int32),
+            block_table_tensor=torch.from_numpy(bt).to(DEV), slot_mapping=torch.from_numpy(slots).to(DEV))
+        md = be.TriangleMixAttentionBackend.get_builder_cls()(types.SimpleNamespace(block_size=page), ["l0"], None,
+                                                              torch.device(DEV)).build(0, common)
+        assert md.whole_prompts
+        impl = be.TriangleMixAttentionBackend.get_impl_cls()(
+            H, D, scale, Hkv, None, None, "auto", None, "decoder", None,
+            trianglemix_config=TriangleMixConfig(num_triangle_layers=1), layer_idx=0)
+        kv_cache = torch.zeros(be.TriangleMixAttentionBackend.get_kv_cache_shape(nblk, page, Hkv, D),
+                               dtype=torch.bfloat16, device=DEV)
+        out = torch.zeros((T, H * D), dtype=torch.bfloat16, device=DEV)
+        impl.forward(None, qd, kd, vd, kv_cache, md, output=out)
+        # what follows on the caller's stream sees the finished cache: read it on that stream, no device-wide wait
+        flat = kv_cache.view(2, nblk * page, Hkv, D)[:, torch.from_numpy(slots).to(DEV)].clone()
+        torch.cuda.current_stream().synchronize()
+        assert torch.equal(flat[0], kd) and torch.equal(flat[1], vd)
+        results.append((out.clone(), kv_cache.clone()))
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+    got = results[0][0].float().cpu().numpy().reshape(T, H, D)
+    ref = np.zeros((T, H, D))
+    for b, s in enumerate(seq_lens):
+        ref[cu[b]:cu[b + 1]] = orc.varlen_gqa_attention(q[cu[b]:cu[b + 1]], lambda _: ks[b], lambda _: vs[b], [0, s], [s],
+                                                        scale, "triangle" if s > 2048 else "causal", 4, 32, 64)
+    err = np.abs(got - ref)
+    assert np.all(err <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8), err.max()
+
+
 def test_backend_pure_decode_step():
     """A step of decode rows only (the backend then cuts the contexts into 128-tile pieces): every row is
     the dense last row of the pattern, contexts from one page to several pieces."""

@@ -18,6 +18,7 @@ Everything here is host logic; the compute is the HIP library (no CPU fallback).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import ClassVar, Dict, List, Optional, Tuple
 
@@ -90,6 +91,16 @@ class TriangleMixAttentionMetadata:
             self._indices[key] = idx
         return idx
 
+    @property
+    def whole_prompts(self) -> bool:
+        """True when no request of the step has earlier context in the cache (every request brings all of its
+        keys with it: the one-step prefill of one or more prompts)."""
+        w = self.__dict__.get("_whole_prompts")
+        if w is None:
+            w = bool(np.array_equal(np.diff(self.query_start_loc_cpu), self.seq_lens_cpu))
+            self.__dict__["_whole_prompts"] = w
+        return w
+
     def workspace(self, idx: "ops.BlockIndex", num_heads: int, head_size: int, device) -> tuple:
         key = (id(idx), num_heads, head_size)
         ws = self._workspaces.get(key)
@@ -97,6 +108,20 @@ class TriangleMixAttentionMetadata:
             ws = ops.alloc_workspace(idx, num_heads, head_size, device)
             self._workspaces[key] = ws
         return ws
+
+
+# One extra stream per device for the cache write of whole-prompt steps.  TRIANGLEMIX_CACHE_WRITE_STREAM=0
+# keeps everything on the caller's stream.
+_CACHE_WRITE_STREAM = os.environ.get("TRIANGLEMIX_CACHE_WRITE_STREAM", "1") != "0"
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(device: torch.device) -> "torch.cuda.Stream":
+    i = device.index if device.index is not None else torch.cuda.current_device()
+    s = _side_streams.get(i)
+    if s is None:
+        s = _side_streams[i] = torch.cuda.Stream(device=i)
+    return s
 
 
 def _step_flags(m: "TriangleMixAttentionMetadata") -> int:
@@ -267,14 +292,31 @@ class TriangleMixAttentionImpl(_ImplBase):
         q = query.view(-1, self.num_heads, self.head_size)[:n_tok]
         if self.fp8_cache:
             return self._forward_fp8_cache(layer, q, key, value, key_cache, value_cache, m, output)
-        if self.kv_sharing_target_layer_name is None and key is not None and value is not None:
-            ops.reshape_and_cache(key[:n_tok], value[:n_tok], key_cache, value_cache, m.slot_mapping[:n_tok])
+        writes_cache = self.kv_sharing_target_layer_name is None and key is not None and value is not None
         out = output.view(-1, self.num_heads, self.head_size)[:n_tok]
         mode = "triangle" if self.use_triangle else "causal"
         pattern = self.pattern if self.use_triangle else (0, 0, 0)
         tri_min_len = self.tri_min_len if self.use_triangle else 0
         idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len)
         ws = m.workspace(idx, self.num_heads, self.head_size, q.device)
+        if writes_cache and m.whole_prompts and _CACHE_WRITE_STREAM and n_tok > 0:
+            # Whole prompts: every key of the step is in `key` / `value` already, so the attention reads those
+            # rows (request b's key j is row query_start_loc[b] + j) and does not wait for the cache write,
+            # which runs beside it on a second stream and is joined before anything else follows on this one
+            # (32k-token prompt, Qwen3-8B heads: 227 us against 248 us one after the other).
+            main = torch.cuda.current_stream(q.device)
+            side = _side_stream(q.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.reshape_and_cache(key[:n_tok], value[:n_tok], key_cache, value_cache, m.slot_mapping[:n_tok])
+            k_rows = key[:n_tok].view(n_tok, self.num_kv_heads, self.head_size)
+            v_rows = value[:n_tok].view(n_tok, self.num_kv_heads, self.head_size)
+            ops.attention(q, k_rows, v_rows, out, idx, m.query_start_loc, m.seq_lens, self.scale,
+                          cu_seqlens_k=m.query_start_loc, workspace=ws, flags=_step_flags(m))
+            main.wait_stream(side)
+            return output
+        if writes_cache:
+            ops.reshape_and_cache(key[:n_tok], value[:n_tok], key_cache, value_cache, m.slot_mapping[:n_tok])
         ops.attention(q, key_cache, value_cache, out, idx, m.query_start_loc, m.seq_lens, self.scale,
                       block_table=m.block_table, workspace=ws, flags=_step_flags(m))
         return output
