@@ -741,7 +741,7 @@ def test_backend_whole_prompt_step_reads_rows_beside_cache_write(monkeypatch):
     qd, kd, vd = qkv.split([H * D, Hkv * D, Hkv * D], dim=-1)
     qd, kd, vd = qd.view(T, H, D), kd.view(T, Hkv, D), vd.view(T, Hkv, D)
     results = []
-    for overlap in (True, False):
+    for overlap in (False, True):
         monkeypatch.setattr(be, "_CACHE_WRITE_STREAM", overlap)
         common = types.SimpleNamespace(
             num_actual_tokens=T, max_query_len=max(q_lens), max_seq_len=max(seq_lens),
@@ -772,6 +772,31 @@ def test_backend_whole_prompt_step_reads_rows_beside_cache_write(monkeypatch):
                                                         scale, "triangle" if s > 2048 else "causal", 4, 32, 64)
     err = np.abs(got - ref)
     assert np.all(err <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8), err.max()
+    # the next step of the same requests, one new token each, launched straight after on the caller's stream:
+    # it reads the cache the second stream wrote (the prompts of the last pass above, written beside the attention)
+    B = len(seq_lens)
+    q2, k2s, v2s = _rand_case(2025, [1] * B, [1] * B, H, Hkv, D)
+    seq2 = [s + 1 for s in seq_lens]
+    slots2 = np.asarray([int(bt[b, seq_lens[b] // page]) * page + seq_lens[b] % page for b in range(B)], np.int64)
+    cu2 = np.arange(B + 1, dtype=np.int32)
+    common2 = types.SimpleNamespace(
+        num_actual_tokens=B, max_query_len=1, max_seq_len=max(seq2),
+        query_start_loc=torch.from_numpy(cu2).to(DEV), query_start_loc_cpu=torch.from_numpy(cu2),
+        seq_lens=torch.tensor(seq2, dtype=torch.int32, device=DEV), seq_lens_cpu=torch.tensor(seq2, dtype=torch.int32),
+        block_table_tensor=torch.from_numpy(bt).to(DEV), slot_mapping=torch.from_numpy(slots2).to(DEV))
+    md2 = be.TriangleMixAttentionBackend.get_builder_cls()(types.SimpleNamespace(block_size=page), ["l0"], None,
+                                                           torch.device(DEV)).build(0, common2)
+    assert not md2.whole_prompts
+    out2 = torch.zeros((B, H * D), dtype=torch.bfloat16, device=DEV)
+    impl.forward(None, qd, kd, vd, kv_cache, md, output=out)  # the prompts again, then the decode step behind it
+    impl.forward(None, _to_dev(q2, torch.bfloat16), _to_dev(np.concatenate(k2s), torch.bfloat16),
+                 _to_dev(np.concatenate(v2s), torch.bfloat16), kv_cache, md2, output=out2)
+    torch.cuda.synchronize()
+    ks2 = [np.concatenate([ks[b], k2s[b]]) for b in range(B)]
+    vs2 = [np.concatenate([vs[b], v2s[b]]) for b in range(B)]
+    ref2 = orc.varlen_gqa_attention(q2, lambda b: ks2[b], lambda b: vs2[b], cu2, seq2, scale, "causal", 0, 0, 0)
+    err2 = np.abs(out2.float().cpu().numpy().reshape(B, H, D) - ref2)
+    assert np.all(err2 <= ATOL_F32_OUT + np.abs(ref2) * 2.0 ** -8), err2.max()
 
 
 def test_backend_pure_decode_step():
