@@ -379,3 +379,31 @@ def test_bench_flop_count_equals_mask_population():
                               (200, (3, 6, 8)), (129, (2, 4, 6))):
         assert bench.allowed_pairs(n, si, sl, last, True) == int(orc.triangle_mask(n, si, sl, last).sum())
         assert bench.allowed_pairs(n, si, sl, last, False) == n * (n + 1) // 2
+
+
+def test_index_sizes_run_lengths_on_long_requests():
+    """The host-side sizing answers for runs of q-blocks at once inside long triangle requests (every full
+    q-block between the first few and the trailing dense rows lists the same number of tiles); the totals must
+    equal the oracle's q-block by q-block count for every block height, with context, with the prompt's full
+    length known, with wide windows and sinks, and without a sink or a window at all."""
+    rng = np.random.default_rng(11)
+    m = ops.MODES["triangle"]
+    for case in range(60):
+        bm = int(rng.choice([32, 64, 128]))
+        batch = int(rng.integers(1, 4))
+        seq = rng.integers(1, 5000, size=batch)
+        qlen = np.asarray([int(rng.integers(1, s + 1)) if rng.random() < 0.5 else int(s) for s in seq])
+        si = int(rng.choice([-1, 0, 4, 31, 32, 33, 100]))
+        sl = int(rng.choice([0, 1, 31, 32, 33, 64, 200, 1024]))
+        last = int(rng.choice([0, 1, 64, 65, 300]))
+        chunk = int(rng.choice([2, 16, 64]))
+        full = None if case % 3 else (seq + rng.integers(0, 3000, size=batch)).astype(np.int32)
+        cu = np.concatenate([[0], np.cumsum(qlen)]).astype(np.int32)
+        sz = ops.index_sizes(cu, seq.astype(np.int32), si, sl, last, bm, 32, m, chunk_tiles=chunk, full_lens_cpu=full)
+        rp, ci, _, _ = orc.block_index_closed_form(qlen, seq, si, sl, last, bm, 32, m, full)
+        items, part_ptr = orc.work_items(rp, chunk)
+        got = (sz.num_qblocks, sz.nnz_tiles, sz.num_items, sz.num_partials, sz.num_split_qblocks,
+               sz.max_tiles_per_qblock)
+        want = (len(rp) - 1, len(ci), len(items), int(part_ptr[-1]), int(np.count_nonzero(np.diff(part_ptr))),
+                int(np.max(np.diff(rp))))
+        assert got == want, (case, bm, seq, qlen, si, sl, last, chunk, full)

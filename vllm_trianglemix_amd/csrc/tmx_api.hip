@@ -44,20 +44,22 @@ int tmx_index_sizes(const int32_t* cu_q, const int32_t* seq_lens, const int32_t*
     TMX_CHECK_ARG(ql >= 0 && n >= ql, "tmx_index_sizes: request %d has q_len %d, seq_len %d", b, ql, n);
     const int ctx = n - ql;
     const int nf = full_lens ? tmx::imax(n, full_lens[b]) : n;
-    for (int r0 = 0; r0 < ql; r0 += block_m) {
-      const int r1 = tmx::imin(r0 + block_m, ql);
-      const int cnt =
-          tmx::tile_ranges(tmx::effective_mode(mode, nf, tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, si, sl, last, block_n)
-              .count();
+    const int m = tmx::effective_mode(mode, nf, tri_min_len);
+    const int nq = tmx::ceil_div(ql, block_m);
+    for (int k = 0; k < nq;) {
+      const int r0 = k * block_m, r1 = tmx::imin(r0 + block_m, ql);
+      const int cnt = tmx::tile_ranges(m, ctx + r0, ctx + r1 - 1, n, nf, si, sl, last, block_n).count();
+      const int64_t reps = tmx::same_count_run(m, k, ctx, ql, nf, si, sl, last, block_m, block_n);
       const int pieces = tmx::imax(1, tmx::ceil_div(cnt, chunk_tiles));
-      ++R;
-      nnz += cnt;
-      items += pieces;
+      R += reps;
+      nnz += reps * cnt;
+      items += reps * pieces;
       if (pieces > 1) {
-        parts += pieces;
-        ++split;
+        parts += reps * pieces;
+        split += reps;
       }
       if (cnt > mx) mx = cnt;
+      k += (int)reps;
     }
   }
   TMX_CHECK_ARG(nnz < INT_MAX && items < INT_MAX && R < INT_MAX, "tmx_index_sizes: index exceeds int32 range");
@@ -93,15 +95,19 @@ int tmx_suggest_chunk_tiles(const int32_t* cu_q, const int32_t* seq_lens, const 
     const int ctx = n - ql;
     const int nf = full_lens ? tmx::imax(n, full_lens[b]) : n;
     const int m = tmx::effective_mode(mode, nf, tri_min_len);
-    for (int r0 = 0; r0 < ql; r0 += block_m) {
+    const int nq = tmx::ceil_div(ql, block_m);
+    for (int k = 0; k < nq;) {
+      const int r0 = k * block_m;
       const int i_max = ctx + tmx::imin(r0 + block_m, ql) - 1;
       const int cnt = tmx::tile_ranges(m, ctx + r0, i_max, n, nf, si, sl, last, block_n).count();
+      const int reps = tmx::same_count_run(m, k, ctx, ql, nf, si, sl, last, block_m, block_n);  // > 1: sparse rows
       if (m != TMX_MODE_TRIANGLE || (nf - i_max) < last) dense_tiles += cnt;
       else {
-        sparse_tiles += cnt;
-        ++sparse_blocks;
+        sparse_tiles += (long long)reps * cnt;
+        sparse_blocks += reps;
         sparse_max = tmx::imax(sparse_max, cnt);
       }
+      k += reps;
     }
   }
   int chunk;

@@ -95,6 +95,28 @@ TMX_HD TileRanges tile_ranges(int mode, int i_min, int i_max, int n, int n_full,
   return r;
 }
 
+// Host-side sizing walks a request q-block by q-block; inside a triangle request that would be thousands of
+// identical answers.  Number (>= 1) of consecutive q-blocks, from q-block k on, that list exactly as many tiles
+// as q-block k: past the first few q-blocks (whose window still reaches the sink tiles) and before the trailing
+// dense rows every full q-block lists sink tiles + window tiles, and with block_m a multiple of block_n both
+// ends of the window move by the same whole number of tiles from one q-block to the next.
+TMX_HD int same_count_run(int mode, int k, int ctx, int q_len, int n_full, int si, int sl, int last, int bm, int bn) {
+  if (mode != TMX_MODE_TRIANGLE || bm % bn != 0) return 1;
+  const int full_blocks = q_len / bm;  // q-blocks 0 .. full_blocks - 1 have all bm rows
+  if (k >= full_blocks) return 1;
+  const int i_min = ctx + k * bm, i_max = i_min + bm - 1;
+  if ((n_full - i_max) < last) return 1;    // trailing dense rows
+  if (si >= 0 && i_max < si) return 1;      // still inside the sink columns
+  if (sl >= 0) {
+    if (i_min - sl < 0) return 1;           // window clamped at key 0
+    if (si >= 0 && (i_min - sl) / bn <= si / bn + 1) return 1;  // window tiles touch the sink tiles
+  }
+  // the last q-block with i_max <= n_full - last, i.e. (k' + 1) * bm <= n_full - last - ctx + 1
+  const long long lim = ((long long)n_full - last - ctx + 1) / bm - 1;
+  const long long k_end = lim < full_blocks - 1 ? lim : full_blocks - 1;
+  return k_end >= k ? (int)(k_end - k + 1) : 1;
+}
+
 void set_error(const char* fmt, ...);
 
 #define TMX_CHECK_ARG(cond, ...)      \

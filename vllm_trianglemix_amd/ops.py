@@ -40,6 +40,11 @@ def _stream(device: torch.device) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _np_ptr(a: np.ndarray) -> ctypes.c_void_p:
+    """Address of a (contiguous) numpy array; ``a.ctypes`` builds a helper object per access, ten times as slow."""
+    return ctypes.c_void_p(a.__array_interface__["data"][0])
+
+
 def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
@@ -101,8 +106,8 @@ def index_sizes(cu_seqlens_q_cpu, seq_lens_cpu, si: int, sl: int, last: int, blo
         if fl.shape != sl_.shape:
             raise RuntimeError("full_lens must have one entry per request")
     sz = IndexSizes()
-    check(_lib.load().tmx_index_sizes(cu.ctypes.data_as(ctypes.c_void_p), sl_.ctypes.data_as(ctypes.c_void_p),
-                                      None if fl is None else fl.ctypes.data_as(ctypes.c_void_p), int(sl_.shape[0]), si, sl, last, block_m, block_n, mode, tri_min_len,
+    check(_lib.load().tmx_index_sizes(_np_ptr(cu), _np_ptr(sl_),
+                                      None if fl is None else _np_ptr(fl), int(sl_.shape[0]), si, sl, last, block_m, block_n, mode, tri_min_len,
                                       chunk_tiles,
                                       ctypes.byref(sz)))
     return sz
@@ -124,39 +129,44 @@ def suggest_chunk_tiles(cu_seqlens_q_cpu, seq_lens_cpu, si: int, sl: int, last: 
     sl_ = np.ascontiguousarray(np.asarray(seq_lens_cpu), dtype=np.int32)
     fl = None if full_lens_cpu is None else np.ascontiguousarray(np.asarray(full_lens_cpu), dtype=np.int32)
     out = ctypes.c_int(0)
-    check(_lib.load().tmx_suggest_chunk_tiles(cu.ctypes.data_as(ctypes.c_void_p), sl_.ctypes.data_as(ctypes.c_void_p),
-                                              None if fl is None else fl.ctypes.data_as(ctypes.c_void_p),
+    check(_lib.load().tmx_suggest_chunk_tiles(_np_ptr(cu), _np_ptr(sl_),
+                                              None if fl is None else _np_ptr(fl),
                                               int(sl_.shape[0]), si, sl, last, block_m, block_n, mode, tri_min_len,
                                               int(num_units), int(num_cus), ctypes.byref(out)))
     return int(out.value)
 
 
-@dataclass
 class BlockIndex:
-    """Device-resident packed block-sparse index + work list (all int32)."""
-    row_ptr: torch.Tensor
-    col_idx: torch.Tensor
-    qb_meta: torch.Tensor
-    part_ptr: torch.Tensor
-    items: torch.Tensor
-    split_qb: torch.Tensor
-    totals: torch.Tensor
-    scratch: torch.Tensor
-    sizes: IndexSizes
-    c: Index
-    batch: int
-    block_m: int
-    block_n: int
-    mode: int
-    si: int
-    sl: int
-    last: int
-    chunk_tiles: int
-    tri_min_len: int = 0
-    tile_pages: Optional[torch.Tensor] = None
-    block_table: Optional[torch.Tensor] = None  # kept alive: the C struct points at it
-    full_lens: Optional[torch.Tensor] = None    # (device) kept alive likewise
-    full_lens_cpu: Optional[np.ndarray] = None
+    """Device-resident packed block-sparse index + work list (all int32), in ONE device allocation: the
+    arrays are slices of ``buf`` (16-byte aligned starts), made on demand, so a step pays for one
+    allocation and one launch sequence."""
+    __slots__ = ("buf", "_off", "sizes", "c", "batch", "block_m", "block_n", "mode", "si", "sl", "last",
+                 "chunk_tiles", "tri_min_len", "block_table", "full_lens", "full_lens_cpu")
+
+    def __init__(self, buf, off, sizes, c, batch, block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
+                 block_table, full_lens, full_lens_cpu):
+        self.buf, self._off, self.sizes, self.c = buf, off, sizes, c
+        self.batch, self.block_m, self.block_n, self.mode = batch, block_m, block_n, mode
+        self.si, self.sl, self.last, self.chunk_tiles, self.tri_min_len = si, sl, last, chunk_tiles, tri_min_len
+        # kept alive: the C struct points at them
+        self.block_table, self.full_lens, self.full_lens_cpu = block_table, full_lens, full_lens_cpu
+
+    def _arr(self, name: str) -> torch.Tensor:
+        o, n = self._off[name]
+        return self.buf[o:o + n]
+
+    row_ptr = property(lambda self: self._arr("row_ptr"))          # [R + 1]
+    col_idx = property(lambda self: self._arr("col_idx"))          # [nnz]
+    qb_meta = property(lambda self: self._arr("qb_meta").view(-1, 2))   # [R, 2]
+    part_ptr = property(lambda self: self._arr("part_ptr"))        # [R + 1]
+    items = property(lambda self: self._arr("items").view(-1, 8))  # [items, 8]
+    split_qb = property(lambda self: self._arr("split_qb"))        # [split q-blocks]
+    totals = property(lambda self: self._arr("totals"))            # [8]
+    scratch = property(lambda self: self._arr("scratch"))
+
+    @property
+    def tile_pages(self) -> Optional[torch.Tensor]:                # [nnz, 2] or None
+        return self._arr("tile_pages").view(-1, 2) if "tile_pages" in self._off else None
 
     @property
     def num_qblocks(self) -> int:
@@ -172,7 +182,7 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
                       chunk_tiles: int = DEFAULT_CHUNK_TILES, tri_min_len: int = 0,
                       block_table: Optional[torch.Tensor] = None, page_size: int = 0,
                       full_lens: Optional[torch.Tensor] = None, full_lens_cpu=None) -> BlockIndex:
-    """Build the packed block-sparse index on the device (two launches, no
+    """Build the packed block-sparse index on the device (one allocation, at most two launches, no
     host synchronisation; buffer sizes come from the host copies).  With a
     ``block_table`` (int32 ``[B, max_blocks]``) and ``page_size`` the physical
     pages of every listed tile are resolved as well (paged K/V, ``block_n`` 32).
@@ -200,42 +210,45 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
     sz = index_sizes(cu_h, sl_h, si, sl, last, block_m, block_n, mode, chunk_tiles, tri_min_len, fl_h)
     R, nnz, n_items, n_split = (int(sz.num_qblocks), int(sz.nnz_tiles), int(sz.num_items),
                                 int(sz.num_split_qblocks))
-
-    def i32(n):
-        return torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
-
-    row_ptr, col_idx, qb_meta, part_ptr = i32(R + 1), i32(nnz), i32(2 * R), i32(R + 1)
-    items = torch.empty((max(n_items, 1), 8), dtype=torch.int32, device=dev)
-    split_qb, totals, scratch = i32(n_split), i32(8), i32(batch + 1 + 2 * (R + 1))
-    c = Index()
-    c.row_ptr, c.col_idx, c.qb_meta, c.part_ptr = (row_ptr.data_ptr(), col_idx.data_ptr(), qb_meta.data_ptr(),
-                                                    part_ptr.data_ptr())
-    c.items, c.split_qb, c.totals, c.scratch = (items.data_ptr(), split_qb.data_ptr(), totals.data_ptr(),
-                                                scratch.data_ptr())
-    c.cap_qblocks, c.cap_nnz, c.cap_items, c.cap_split = R, nnz, n_items, n_split
-    c.block_m, c.block_n, c.mode, c.chunk_tiles = block_m, block_n, mode, chunk_tiles
-    c.si, c.sl, c.last, c.batch = si, sl, last, batch
-    c.tri_min_len = tri_min_len
-    tile_pages = None
     if block_table is not None:
         _require_gpu(block_table, "block_table")
         if block_table.dtype != torch.int32 or block_table.dim() != 2 or block_table.stride(1) != 1:
             raise RuntimeError("block_table must be int32 [B, max_blocks] with contiguous rows")
-        tile_pages = torch.empty((max(nnz, 1), 2), dtype=torch.int32, device=dev)
-        c.tile_pages, c.pages_block_table = tile_pages.data_ptr(), block_table.data_ptr()
+    # one allocation; every array starts on a multiple of 4 ints (16 bytes: the alignment the work list needs)
+    off, total = {}, 0
+    for name, n in (("items", 8 * n_items), ("tile_pages", 2 * nnz if block_table is not None else -1),
+                    ("row_ptr", R + 1), ("col_idx", nnz), ("qb_meta", 2 * R), ("part_ptr", R + 1),
+                    ("split_qb", n_split), ("totals", 8), ("scratch", batch + 1 + 2 * (R + 1))):
+        if n < 0:
+            continue
+        off[name] = (total, n)
+        total += (max(n, 1) + 3) & ~3
+    buf = torch.empty((total,), dtype=torch.int32, device=dev)
+    base = buf.data_ptr()
+
+    def at(name):
+        return base + 4 * off[name][0]
+
+    c = Index()
+    c.row_ptr, c.col_idx, c.qb_meta, c.part_ptr = at("row_ptr"), at("col_idx"), at("qb_meta"), at("part_ptr")
+    c.items, c.split_qb, c.totals, c.scratch = at("items"), at("split_qb"), at("totals"), at("scratch")
+    c.cap_qblocks, c.cap_nnz, c.cap_items, c.cap_split = R, nnz, n_items, n_split
+    c.block_m, c.block_n, c.mode, c.chunk_tiles = block_m, block_n, mode, chunk_tiles
+    c.si, c.sl, c.last, c.batch = si, sl, last, batch
+    c.tri_min_len = tri_min_len
+    if block_table is not None:
+        c.tile_pages, c.pages_block_table = at("tile_pages"), block_table.data_ptr()
         c.pages_block_table_stride, c.pages_page_size = block_table.stride(0), int(page_size)
     else:
         c.tile_pages, c.pages_block_table, c.pages_block_table_stride, c.pages_page_size = None, None, 0, 0
     c.full_lens = None if full_lens is None else full_lens.data_ptr()
-    c.full_lens_host = None if fl_h is None else fl_h.ctypes.data_as(ctypes.c_void_p)
+    c.full_lens_host = None if fl_h is None else _np_ptr(fl_h)
     with torch.cuda.device(dev):
         check(_lib.load().tmx_build_block_index(ctypes.byref(c), _ptr(cu_seqlens_q), _ptr(seq_lens),
-                                                cu_h.ctypes.data_as(ctypes.c_void_p),
-                                                sl_h.ctypes.data_as(ctypes.c_void_p), _stream(dev)))
-    return BlockIndex(row_ptr[:R + 1], col_idx[:nnz], qb_meta[:2 * R].view(R, 2) if R else qb_meta[:0].view(0, 2),
-                      part_ptr[:R + 1], items[:n_items], split_qb[:n_split], totals, scratch, sz, c, batch,
-                      block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
-                      None if tile_pages is None else tile_pages[:nnz], block_table, full_lens, fl_h)
+                                                _np_ptr(cu_h),
+                                                _np_ptr(sl_h), _stream(dev)))
+    return BlockIndex(buf, off, sz, c, batch, block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
+                      block_table, full_lens, fl_h)
 
 
 # --------------------------------------------------------------------------- attention
