@@ -42,8 +42,11 @@ CHUNK_TILES = 64  # key tiles per work item of the dense trailing rows (64 x 32 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--settle-ms", type=float, default=150.0,
+                    help="untimed steps run for this long before the warm-up steps: an idle GPU needs tens of "
+                         "milliseconds of load before its clocks settle (0.25 ms steps: 10 warm-up steps are 2.5 ms)")
     ap.add_argument("--seq-len", type=int, default=32768)
     ap.add_argument("--oproj", action="store_true", help="also time o_proj GEMM + all-reduce (reported separately)")
     ap.add_argument("--no-baselines", action="store_true", help="skip the dense and CPU baselines")
@@ -178,6 +181,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # an idle GPU first: its clocks settle after tens of milliseconds of load, far more than a few 0.25 ms steps
+    # (measured on one box: 248 us per step after 10 warm-up steps, 207 us after 200)
+    t_settle = time.perf_counter() + args.settle_ms * 1e-3
+    while time.perf_counter() < t_settle:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -333,7 +343,7 @@ def main():
         line = {
             "metric": "prefill tokens/sec (TriangleMix attention op, index build included), Qwen3-8B 32k ctx",
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "settle_ms": args.settle_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Qwen3-8B bf16 seq_len={n} TriangleMix prefill (one attention layer: block-index "
                                    f"build + masked attention), sink/window/last={PATTERN}, paged KV page {PAGE}",

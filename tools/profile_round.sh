@@ -5,7 +5,7 @@ tag=$1
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --no-baselines > $out/bench_line.json 2> $out/bench.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-baselines > $out/bench_line.json 2> $out/bench.err || exit 1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $GRAFT_REPO_ROOT/tools/run_once.py triangle 32768 5 64 1 > $out/fetch.log 2>&1 || exit 2
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $GRAFT_REPO_ROOT/tools/run_once.py triangle 32768 5 64 1 > $out/write.log 2>&1 || exit 3
 python3 $GRAFT_REPO_ROOT/tools/traffic.py $out/fetch $out/write 32768 $out/traffic.json
