@@ -2,7 +2,7 @@
 # usage (GPU box): LIBS="a.so b.so" bash tools/ab_bench.sh  -> step and kernel time of bench.py for each build, alternating
 for r in 1 2 3; do
   for lib in $LIBS; do
-    TMX_LIB_PATH=$PWD/$lib timeout -k 10 150 python bench.py --no-baselines --steps 200 --warmup 50 > /tmp/ab_bench_out.json || exit 1
+    TMX_LIB_PATH=$PWD/$lib timeout -k 10 150 python bench.py --no-baselines > /tmp/ab_bench_out.json || exit 1
     python - "$lib" <<'P'
 import json, sys
 d = json.loads(open('/tmp/ab_bench_out.json').read().strip().splitlines()[-1])
