@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=4096, help="query rows of the CPU-baseline sample")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="rehearsal on one GPU: rank 0's share of an N-GPU job (N prompts, heads / N), no process group")
+    ap.add_argument("--chunk-tiles", type=int, default=0,
+                    help="piece length of the dense rows in key tiles (0: the library's advice for the batch)")
     ap.add_argument("--cpu-heads", type=int, default=8, help="heads of the CPU-baseline sample")
     return ap.parse_args()
 
@@ -160,8 +162,13 @@ def main():
     def build(mode):
         # pages of every listed tile are resolved by the builder (block table lookups leave the attention loop);
         # the piece length is the library's advice for this batch (one piece of the dense rows per CU: 64 tiles here)
-        chunk = ops.suggest_chunk_tiles(inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn, ops.MODES[mode],
-                                        ops.units_per_item(H, Hkv)) if mode == "triangle" else CHUNK_TILES
+        if mode != "triangle":
+            chunk = CHUNK_TILES
+        elif args.chunk_tiles > 0:
+            chunk = args.chunk_tiles
+        else:
+            chunk = ops.suggest_chunk_tiles(inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn, ops.MODES[mode],
+                                            ops.units_per_item(H, Hkv))
         return ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn,
                                      ops.MODES[mode], chunk_tiles=chunk, block_table=inp["block_table"],
                                      page_size=PAGE)
