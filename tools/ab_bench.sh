@@ -7,7 +7,7 @@ for r in 1 2 3; do
     python - "$lib $ARGS" <<'P'
 import json, sys
 d = json.loads(open('/tmp/ab_bench_out.json').read().strip().splitlines()[-1])
-print(f"{sys.argv[1]:40s} step {d['ms_per_step']*1e3:7.1f} us  kernel {d['roofline']['kernel_ms']*1e3:7.1f} us  {d['value']/1e6:6.1f} M tokens/s", flush=True)
+print(f"{sys.argv[1]:40s} step {d['ms_per_step']*1e3:7.1f} us  kernel {d['roofline']['kernel_ms']*1e3:7.1f} us  combine {d['roofline']['combine_ms']*1e3:5.1f} us  index {d['roofline']['index_build_ms']*1e3:5.1f} us  {d['value']/1e6:6.1f} M tokens/s", flush=True)
 P
   done
 done
