@@ -37,7 +37,12 @@ ops.reshape_and_cache(k, v, kc, vc, slots)
 bt = perm.view(1, -1).to(dev)
 
 def timed(fn, iters):
-    for _ in range(3): fn()
+    # an idle GPU needs tens of milliseconds of load before its clocks settle
+    import time
+    t_end = time.perf_counter() + 0.15
+    while time.perf_counter() < t_end:
+        for _ in range(10): fn()
+        torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for a, b in evs:
         a.record(); fn(); b.record()
