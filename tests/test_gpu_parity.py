@@ -512,6 +512,36 @@ def test_attention_bias_and_fully_masked_rows():
     assert np.abs(got2 - ref2).max() <= ATOL_F32_OUT
 
 
+def test_empty_inputs():
+    """A request without query rows between two others (its keys are never touched), and a step with no
+    request at all: the index is empty and the attention call is a no-op that leaves the output alone."""
+    ops = _ops()
+    H, Hkv, D = 8, 2, 128
+    q_lens, seq_lens = [40, 0, 70], [40, 25, 2100]
+    q, ks, vs = _rand_case(99, q_lens, seq_lens, H, Hkv, D)
+    scale = D ** -0.5
+    for paged in (False, True):
+        got = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, "triangle", (4, 32, 64), paged=paged, gate=2048)
+        ref = np.zeros_like(got, dtype=np.float64)
+        cu = np.concatenate([[0], np.cumsum(q_lens)])
+        for b, (ql, s) in enumerate(zip(q_lens, seq_lens)):
+            if ql:
+                ref[cu[b]:cu[b + 1]] = orc.varlen_gqa_attention(q[cu[b]:cu[b + 1]], lambda _: ks[b], lambda _: vs[b], [0, ql], [s],
+                                                                scale, "triangle" if s > 2048 else "causal", 4, 32, 64)
+        assert np.abs(got - ref).max() <= ATOL_F32_OUT
+    # no request at all
+    cu_h, sl_h = np.zeros((1,), np.int32), np.zeros((0,), np.int32)
+    cu, sld = torch.from_numpy(cu_h).to(DEV), torch.from_numpy(sl_h).to(DEV)
+    idx = ops.build_block_index(cu, sld, cu_h, sl_h, 4, 32, 64, ops.attention_block_m(H, Hkv), 32, ops.MODES["triangle"])
+    torch.cuda.synchronize()
+    assert idx.num_qblocks == 0 and idx.nnz_tiles == 0 and int(idx.totals[0]) == 0
+    qe = torch.zeros((0, H, D), dtype=torch.bfloat16, device=DEV)
+    ke = torch.zeros((0, Hkv, D), dtype=torch.bfloat16, device=DEV)
+    oe = torch.zeros((0, H, D), dtype=torch.bfloat16, device=DEV)
+    ops.attention(qe, ke, ke, oe, idx, cu, sld, scale, cu_seqlens_k=cu)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("n,paged,H,Hkv,cache", [
     (8192, False, 32, 8, "bf16"),   # Qwen3-8B, 8k prompt
     (32768, True, 32, 8, "bf16"),   # Qwen3-8B, 32k prompt (the benchmark's workload)
