@@ -547,6 +547,7 @@ def test_empty_inputs():
     (32768, True, 32, 8, "bf16"),   # Qwen3-8B, 32k prompt (the benchmark's workload)
     (32768, True, 16, 2, "bf16"),   # Qwen3-32B, one of 4 head shards
     (65536, True, 8, 1, "fp8"),     # 64-head / 8-kv-head model, one of 8 head shards, fp8 cache
+    (131072, True, 8, 2, "bf16"),   # a 128k-token prompt (the index is then built by two launches)
 ])
 def test_attention_properties_at_full_size(n, paged, H, Hkv, cache):
     """Size-independent properties at the BASELINE sizes and head shards (N = 8192 contiguous K/V; the
@@ -616,7 +617,8 @@ def test_attention_properties_at_full_size(n, paged, H, Hkv, cache):
             outs.append(o)
         lin = (outs[0] + outs[1] - outs[2]).abs().max().item()
         assert lin < 0.05  # v1 + v2 is re-rounded to bf16: 2^-8 relative on values up to ~8
-        assert (outs[3] - 1.0).abs().max().item() < 1e-5
+        # fp32 sums of up to n products against an fp32 sum of the weights: 4e-6 at 32k keys, 1.1e-5 at 128k
+        assert (outs[3] - 1.0).abs().max().item() < (1e-5 if n <= 65536 else 3e-5)
         seen_k, seen_v = k, v1
     assert not torch.isnan(outs[0]).any()
     rows = [0, 5, 40, n // 2 + 17, n - 1 - 70, n - 64, n - 63, n - 10, n - 1]
