@@ -36,7 +36,6 @@ MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (no sparsity)
 QWEN3_8B = dict(num_heads=32, num_kv_heads=8, head_dim=128, hidden=4096)
 PATTERN = (4, 32, 64)  # sink, window, last: the reference defaults
 PAGE = 16
-CHUNK_TILES = 64  # key tiles per work item of the dense trailing rows (64 x 32 = 2048 keys)
 
 
 def parse():
@@ -162,9 +161,7 @@ def main():
     def build(mode):
         # pages of every listed tile are resolved by the builder (block table lookups leave the attention loop);
         # the piece length is the library's advice for this batch (one piece of the dense rows per CU: 64 tiles here)
-        if mode != "triangle":
-            chunk = CHUNK_TILES
-        elif args.chunk_tiles > 0:
+        if mode == "triangle" and args.chunk_tiles > 0:
             chunk = args.chunk_tiles
         else:
             chunk = ops.suggest_chunk_tiles(inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn, ops.MODES[mode],
@@ -311,8 +308,10 @@ def main():
             outd = torch.empty_like(qd)
             cu_dh, sl_dh = np.arange(Bd + 1, dtype=np.int32), np.full((Bd,), Nd, np.int32)
             cu_d, sl_d = torch.from_numpy(cu_dh).to(dev), torch.from_numpy(sl_dh).to(dev)
+            chunk_d = ops.suggest_chunk_tiles(cu_dh, sl_dh, si, sl, last, bm, bn, ops.MODES["triangle"],
+                                              ops.units_per_item(H, Hkv))
             idx_d = ops.build_block_index(cu_d, sl_d, cu_dh, sl_dh, si, sl, last, bm, bn, ops.MODES["triangle"],
-                                          chunk_tiles=128, block_table=btd, page_size=PAGE)
+                                          chunk_tiles=chunk_d, block_table=btd, page_size=PAGE)
             work_d = ops.alloc_workspace(idx_d, H, D, dev)
 
             def decode():

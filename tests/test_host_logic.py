@@ -165,8 +165,13 @@ def test_chunk_tiles_advice():
     # a rank's share of an 8-GPU job: 8 prompts, 4 query heads on 1 K/V head
     assert ops.suggest_chunk_tiles(np.arange(9) * 32768, [32768] * 8, 4, 32, 64, 32, 32, ops.MODES["triangle"], 1,
                                    num_cus=256) == 64
-    assert ops.suggest_chunk_tiles(np.arange(65), [8192] * 64, 4, 32, 64, 32, 32, ops.MODES["triangle"], u, num_cus=256) == 128
-    assert ops.suggest_chunk_tiles([0, 32768], [32768], 4, 32, 64, 32, 32, ops.MODES["causal"], u, num_cus=256) == 64
+    # decode steps: one piece per workgroup slot (2 x 256), between 8 and 512 tiles
+    for b, n, want in ((64, 8192, 256), (8, 32768, 128), (4, 16384, 32), (1, 8192, 8), (1, 131072, 64), (256, 2048, 256)):
+        assert ops.suggest_chunk_tiles(np.arange(b + 1), [n] * b, 4, 32, 64, 32, 32, ops.MODES["triangle"], u,
+                                       num_cus=256) == want, (b, n)
+    # causal prompts: between 64 and 256 tiles
+    for n, want in ((32768, 256), (8192, 256), (2048, 64)):
+        assert ops.suggest_chunk_tiles([0, n], [n], 4, 32, 64, 32, 32, ops.MODES["causal"], u, num_cus=256) == want
     # chunked prefill: a middle chunk of a long prompt has sparse rows only (no piece to balance): the default
     assert ops.suggest_chunk_tiles([0, 4096], [8192], 4, 32, 64, 32, 32, ops.MODES["triangle"], u, num_cus=256,
                                    full_lens_cpu=[32768]) == 64

@@ -27,8 +27,12 @@ for chunk in chunks:
     idx = ops.build_block_index(cu, sl, cu_h, sl_h, 4, 32, 64, bm, 32, ops.MODES["triangle"], chunk_tiles=chunk,
                                 block_table=bt, page_size=page)
     ws = ops.alloc_workspace(idx, H, D, dev)
-    for _ in range(3):
-        ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=ws, flags=TMX_ATTN_SHORT_QUERIES)
+    import time
+    t_end = time.perf_counter() + 0.15  # an idle GPU needs tens of milliseconds of load before its clocks settle
+    while time.perf_counter() < t_end:
+        for _ in range(10):
+            ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=ws, flags=TMX_ATTN_SHORT_QUERIES)
+        torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
     for a, b in evs:
         a.record()
