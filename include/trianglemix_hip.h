@@ -138,8 +138,9 @@ int tmx_index_sizes(const int32_t* cu_seqlens_q_host, const int32_t* seq_lens_ho
  * num_kv_heads * (group size / heads per workgroup) = num_kv_heads for group sizes that are
  * multiples of 4; num_cus <= 0 queries the current device.  Measured on MI355X: a prefill with sparse
  * and dense rows runs fastest when the dense rows make one piece per CU (8192 tokens: 16 tiles,
- * 32768: 64, 65536: 128 for Qwen3-8B's heads); batches of dense rows only get one piece per workgroup
- * slot of the chip (two per CU), within 8..512 tiles for decode steps and 64..256 for causal prompts. */
+ * 32768: 64, 65536: 128 for Qwen3-8B's heads; decode rows in the same step ask for pieces of up to 32
+ * tiles); batches of dense rows only get one piece per workgroup slot of the chip (two per CU), within
+ * 8..512 tiles for decode steps and 64..256 for causal prompts. */
 int tmx_suggest_chunk_tiles(const int32_t* cu_seqlens_q_host, const int32_t* seq_lens_host,
                             const int32_t* full_lens_host /* or NULL */, int batch, int si, int sl, int last,
                             int block_m, int block_n, int mode, int tri_min_len, int units_per_item, int num_cus,

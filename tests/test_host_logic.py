@@ -169,6 +169,14 @@ def test_chunk_tiles_advice():
     for b, n, want in ((64, 8192, 256), (8, 32768, 128), (4, 16384, 32), (1, 8192, 8), (1, 131072, 64), (256, 2048, 256)):
         assert ops.suggest_chunk_tiles(np.arange(b + 1), [n] * b, 4, 32, 64, 32, 32, ops.MODES["triangle"], u,
                                        num_cus=256) == want, (b, n)
+    # a prompt with sparse rows and decode rows in one step: the prompt's dense rows make one piece per CU, the
+    # decode rows ask for pieces of up to 32 tiles
+    def mixed(p, b, n):
+        q = [p] + [1] * b
+        return ops.suggest_chunk_tiles(np.concatenate([[0], np.cumsum(q)]), [p] + [n] * b, 4, 32, 64, 32, 32,
+                                       ops.MODES["triangle"], u, tri_min_len=2049, num_cus=256)
+    assert mixed(8192, 32, 4096) == 32 and mixed(32768, 8, 8192) == 64 and mixed(2100, 64, 8192) == 32
+    assert mixed(2048, 64, 8192) == 256  # a prompt below the gate is attended causally: dense rows only
     # causal prompts: between 64 and 256 tiles
     for n, want in ((32768, 256), (8192, 256), (2048, 64)):
         assert ops.suggest_chunk_tiles([0, n], [n], 4, 32, 64, 32, 32, ops.MODES["causal"], u, num_cus=256) == want

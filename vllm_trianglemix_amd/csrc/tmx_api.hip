@@ -83,8 +83,9 @@ int tmx_suggest_chunk_tiles(const int32_t* cu_q, const int32_t* seq_lens, const 
     TMX_CHECK_HIP(hipGetDevice(&dev));
     TMX_CHECK_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  // dense rows (the trailing rows of the pattern, every row of a causal request) against sparse rows
-  long long dense_tiles = 0, sparse_tiles = 0, sparse_blocks = 0;
+  // dense rows (the trailing rows of the pattern, every row of a causal request) against sparse rows; the dense
+  // rows of requests with up to 16 query rows (decode) apart: their pieces stream K/V for next to no arithmetic
+  long long dense_long = 0, dense_short = 0, sparse_blocks = 0;
   int sparse_max = 0;
   bool decode_only = true;
   for (int b = 0; b < batch; ++b) {
@@ -101,32 +102,39 @@ int tmx_suggest_chunk_tiles(const int32_t* cu_q, const int32_t* seq_lens, const 
       const int i_max = ctx + tmx::imin(r0 + block_m, ql) - 1;
       const int cnt = tmx::tile_ranges(m, ctx + r0, i_max, n, nf, si, sl, last, block_n).count();
       const int reps = tmx::same_count_run(m, k, ctx, ql, nf, si, sl, last, block_m, block_n);  // > 1: sparse rows
-      if (m != TMX_MODE_TRIANGLE || (nf - i_max) < last) dense_tiles += cnt;
-      else {
-        sparse_tiles += (long long)reps * cnt;
+      if (m != TMX_MODE_TRIANGLE || (nf - i_max) < last) {
+        (ql > 16 ? dense_long : dense_short) += cnt;
+      } else {
         sparse_blocks += reps;
         sparse_max = tmx::imax(sparse_max, cnt);
       }
       k += reps;
     }
   }
+  const long long dense_tiles = dense_long + dense_short;
+  const long long slots = 2ll * num_cus;  // two workgroups are resident per CU
   int chunk;
   if (dense_tiles == 0) {
     chunk = tmx::imax(64, sparse_max);  // nothing to split
-  } else if (sparse_blocks == 0 || sparse_tiles * 4 < dense_tiles) {
-    // (almost) only dense rows: one piece per workgroup slot of the chip (two per CU) when that is possible.
+  } else if (sparse_blocks == 0) {
+    // only dense rows: one piece per workgroup slot of the chip when that is possible.
     // Decode steps (measured, 256 CUs, 32 / 8 heads): 1 x 8192 keys 25 us with 8-tile pieces against 106 us with
     // 128; 4 x 16384: 56 us (32 tiles) against 109 us; 64 x 8192: 389 us (256 tiles) against 402 us.  Prompts
     // attended causally: pieces no shorter than 64 tiles (their partial results cost more than the balance gains:
     // 8192 tokens unsplit 0.90 ms against 1.10 ms in 64-tile pieces) and no longer than 256 (32768 tokens: 17.1 ms
     // against 18.5 ms with 512).
-    const long long c = (dense_tiles * units_per_item + 2ll * num_cus - 1) / (2ll * num_cus);
+    const long long c = (dense_tiles * units_per_item + slots - 1) / slots;
     if (decode_only) chunk = (int)(c < 8 ? 8 : (c > 512 ? 512 : c));
     else chunk = (int)(c < 64 ? 64 : (c > 256 ? 256 : c));
   } else {
-    // mixed: one piece of the dense rows per CU, so that every CU runs one arithmetic-bound piece beside one
-    // workgroup of memory-bound sparse rows (two workgroups are resident per CU)
-    const long long c = (dense_tiles * units_per_item + num_cus - 1) / num_cus;
+    // sparse and dense rows: one piece of the prompts' dense rows per CU, so that every CU runs one arithmetic-bound
+    // piece beside one workgroup of memory-bound sparse rows.  Decode rows in the same step ask for little: pieces
+    // of up to 32 tiles, one per workgroup slot (8192-token prompt + 32 decode rows over 4096 keys: 180 us with
+    // 32 tiles, 220 us with 72, 384 us with 256).
+    long long c = (dense_long * units_per_item + num_cus - 1) / num_cus;
+    long long cd = (dense_short * units_per_item + slots - 1) / slots;
+    if (cd > 32) cd = 32;
+    if (cd > c) c = cd;
     chunk = (int)(c < 8 ? 8 : (c > 512 ? 512 : c));
     chunk = tmx::imax(chunk, sparse_max);  // sparse rows stay whole
   }
