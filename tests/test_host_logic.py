@@ -174,7 +174,7 @@ def test_chunk_tiles_advice():
     def mixed(p, b, n):
         q = [p] + [1] * b
         return ops.suggest_chunk_tiles(np.concatenate([[0], np.cumsum(q)]), [p] + [n] * b, 4, 32, 64, 32, 32,
-                                       ops.MODES["triangle"], u, tri_min_len=2049, num_cus=256)
+                                       ops.MODES["triangle"], u, tri_min_len=2048, num_cus=256)
     assert mixed(8192, 32, 4096) == 32 and mixed(32768, 8, 8192) == 64 and mixed(2100, 64, 8192) == 32
     assert mixed(2048, 64, 8192) == 256  # a prompt below the gate is attended causally: dense rows only
     # causal prompts: between 64 and 256 tiles
@@ -322,7 +322,7 @@ def test_impl_constructor_rules():
     on = TriangleMixAttentionImpl(32, 128, 0.088, 8, None, None, "auto", None, "decoder", None,
                                   trianglemix_config=cfg, layer_idx=1)
     off = TriangleMixAttentionImpl(32, 128, 0.088, 8, None, None, "auto", trianglemix_config=cfg, layer_idx=2)
-    assert on.use_triangle and not off.use_triangle and on.pattern == (4, 32, 64) and on.tri_min_len == 2049
+    assert on.use_triangle and not off.use_triangle and on.pattern == (4, 32, 64) and on.tri_min_len == 2048
     flag = TriangleMixAttentionImpl(16, 64, 0.125, 8, None, None, "auto", use_triangle=True, num_sink_tokens=2,
                                     sliding_window_size=8, num_last_tokens=16)
     assert flag.use_triangle and flag.pattern == (2, 8, 16)

@@ -36,10 +36,10 @@ sl_h = np.asarray(seq_lens, np.int32)
 cu, sl = torch.from_numpy(cu_h).to(dev), torch.from_numpy(sl_h).to(dev)
 bm = ops.attention_block_m(H, Hkv)
 advice = ops.suggest_chunk_tiles(cu_h, sl_h, 4, 32, 64, bm, 32, ops.MODES["triangle"], ops.units_per_item(H, Hkv),
-                                 tri_min_len=2049)
+                                 tri_min_len=2048)
 for chunk in chunks + [advice]:
     idx = ops.build_block_index(cu, sl, cu_h, sl_h, 4, 32, 64, bm, 32, ops.MODES["triangle"], chunk_tiles=chunk,
-                                tri_min_len=2049, block_table=bt, page_size=page)
+                                tri_min_len=2048, block_table=bt, page_size=page)
     ws = ops.alloc_workspace(idx, H, D, dev)
     run = lambda: ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=ws)
     t_end = time.perf_counter() + 0.15

@@ -18,6 +18,7 @@ Everything here is host logic; the compute is the HIP library (no CPU fallback).
 """
 from __future__ import annotations
 
+import enum
 import os
 from dataclasses import dataclass, field
 from typing import ClassVar, Dict, List, Optional, Tuple
@@ -41,6 +42,35 @@ except Exception:  # vLLM (or one of its dependencies) is not installed
         pass
 
     _DECODER = "decoder"  # vllm/attention/backends/abstract.py:17-24
+
+try:  # pragma: no cover - depends on the host installation
+    from vllm.v1.attention.backends.utils import AttentionCGSupport
+    from vllm.v1.attention.backends.utils import AttentionMetadataBuilder as _BuilderBase
+except Exception:
+    class AttentionCGSupport(enum.Enum):
+        """Stand-in with the member names and values of vllm/v1/attention/backends/utils.py:215-229: the
+        model runner compares ``builder.cudagraph_support.value`` across builders
+        (vllm/v1/worker/gpu_model_runner.py:3612-3619)."""
+        ALWAYS = 3
+        UNIFORM_BATCH = 2
+        UNIFORM_SINGLE_TOKEN_DECODE = 1
+        NEVER = 0
+
+    class _BuilderBase:  # the members vllm/v1/attention/backends/utils.py:232-341 gives every builder
+        cudagraph_support: ClassVar["AttentionCGSupport"] = AttentionCGSupport.NEVER
+        reorder_batch_threshold: Optional[int] = None
+
+        def reorder_batch(self, input_batch, scheduler_output) -> bool:
+            raise NotImplementedError
+
+        def build_for_cudagraph_capture(self, common_attn_metadata):
+            return self.build(common_prefix_len=0, common_attn_metadata=common_attn_metadata)
+
+        def build_for_drafting(self, common_attn_metadata, draft_index: int):
+            return self.build(common_prefix_len=0, common_attn_metadata=common_attn_metadata, fast_build=True)
+
+        def use_cascade_attention(self, *args, **kwargs) -> bool:
+            return False
 
 
 @dataclass
@@ -130,10 +160,12 @@ def _step_flags(m: "TriangleMixAttentionMetadata") -> int:
     return TMX_ATTN_SHORT_QUERIES if m.max_query_len <= 16 else 0
 
 
-class TriangleMixMetadataBuilder:
-    """``AttentionMetadataBuilder`` counterpart (utils.py:232-341; rocm_attn.py:60-135)."""
-    cudagraph_support: ClassVar[str] = "NEVER"   # the index depends on the batch: rebuilt every step
-    reorder_batch_threshold: ClassVar[Optional[int]] = None
+class TriangleMixMetadataBuilder(_BuilderBase):
+    """``AttentionMetadataBuilder`` subclass (utils.py:232-341; rocm_attn.py:60-135)."""
+    # the index depends on the batch and is rebuilt every step on the host side of the step: no graph replay
+    # (utils.py:215-239; read as ``.value`` at gpu_model_runner.py:3617)
+    cudagraph_support: ClassVar[AttentionCGSupport] = AttentionCGSupport.NEVER
+    reorder_batch_threshold: Optional[int] = None
 
     def __init__(self, kv_cache_spec, layer_names: List[str], vllm_config, device: torch.device):
         self.kv_cache_spec = kv_cache_spec
@@ -166,7 +198,7 @@ class TriangleMixMetadataBuilder:
             page_size=self.block_size, prompt_lens=prompt_dev, prompt_lens_cpu=prompt_cpu)
 
     def build_for_cudagraph_capture(self, common_attn_metadata) -> TriangleMixAttentionMetadata:
-        return self.build(0, common_attn_metadata)
+        return self.build(common_prefix_len=0, common_attn_metadata=common_attn_metadata)
 
     def use_cascade_attention(self, *args, **kwargs) -> bool:
         return False
@@ -272,8 +304,9 @@ class TriangleMixAttentionImpl(_ImplBase):
             use_triangle = trianglemix_config is not None and trianglemix_config.uses_triangle(self.layer_idx)
         self.use_triangle = bool(use_triangle)
         # requests of at most this many tokens keep plain causal attention: the reference applies
-        # its masks only above the gate (trianglemix_attention.py:330-332)
-        self.tri_min_len = int(short_sequence_gate) + 1
+        # its masks only above the gate (``seq_len <= 2048`` gives no mask, a 2049-token request gets
+        # the triangle: trianglemix_attention.py:330-332); the library's rule is ``n <= tri_min_len``
+        self.tri_min_len = int(short_sequence_gate)
 
     def forward(self, layer, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, kv_cache: torch.Tensor,
                 attn_metadata: Optional[TriangleMixAttentionMetadata], output: Optional[torch.Tensor] = None,

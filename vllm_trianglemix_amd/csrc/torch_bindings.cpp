@@ -268,3 +268,13 @@ TORCH_LIBRARY(_trianglemix_C, m) {
         "Tensor block_table, Tensor seq_lens, Tensor cu_seqlens_k, int max_seq_len, float k_scale, float v_scale) -> ()");
   m.impl("trianglemix_gather_dequant_kv_fp8", c10::DispatchKey::CUDA, &gather_dequant_kv_fp8);
 }
+
+// The extension is also a Python module, so that a plain `import` of the shared object runs the
+// TORCH_LIBRARY block above: the reference's REGISTER_EXTENSION (csrc/core/registration.h:13-27), which is
+// how vllm/platforms/rocm.py:32-40 loads vllm._C / vllm._rocm_C.
+#include <Python.h>
+
+extern "C" __attribute__((visibility("default"))) PyObject* PyInit__trianglemix_C() {
+  static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_trianglemix_C", nullptr, 0, nullptr};
+  return PyModule_Create(&module);
+}

@@ -5,6 +5,7 @@ vllm/_custom_ops.py:153-196 wraps ``torch.ops._rocm_C.*``).  The ctypes
 binding in ``_lib.py`` and this one call the same library entry points."""
 from __future__ import annotations
 
+import importlib
 import os
 
 import torch
@@ -20,6 +21,8 @@ def load():
     if not _loaded:
         if not os.path.exists(BINDING_PATH):
             raise ImportError(f"{BINDING_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}`")
-        torch.ops.load_library(BINDING_PATH)
+        # a plain import: the shared object is a Python extension module whose load registers the ops
+        # (PyInit__trianglemix_C, the reference's REGISTER_EXTENSION, csrc/core/registration.h:13-27)
+        importlib.import_module(__package__ + "._trianglemix_C")
         _loaded = True
     return torch.ops._trianglemix_C
