@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TMX_ABI_VERSION 2
+#define TMX_ABI_VERSION 3
 
 enum {
   TMX_OK = 0,
@@ -236,6 +236,8 @@ typedef struct tmx_attention_args_t {
 
   const tmx_index_t* index;
   int64_t num_items, num_partials, num_split_qblocks; /* from tmx_index_sizes */
+  int64_t nnz_tiles; /* from tmx_index_sizes (entries of col_idx); 0 = unknown, the capacity is used. Only
+                        the static schedule's weights read it: results never depend on it. */
 
   /* Work area for split q-blocks (device, float32):
    * partial_o [num_partials][num_heads][block_m][head_dim], partial_ml [num_partials][num_heads][block_m][2].
@@ -258,6 +260,22 @@ typedef struct tmx_attention_args_t {
 #define TMX_ATTN_SHORT_QUERIES 4u
 
 int tmx_attention(const tmx_attention_args_t* args, void* stream);
+
+/* ------------------------------------------------------------------------
+ * tmx_attention for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
+ * and results as tmx_attention, except that args->partial_o / partial_ml are ignored: the work area of
+ * the split q-blocks is a fixed array of TMX_STATIC_WORKSPACE_BYTES inside the library's device image
+ * (one copy per GPU, held until the process ends).  Steps whose partials need more
+ * (num_partials * num_heads * block_m * (head_dim + 2) * 4 bytes, the first part rounded up to 256)
+ * fail with TMX_ERR_CAPACITY and launch nothing.  The call allocates nothing and frees nothing.
+ * All calls on one GPU share the array: two calls that overlap in time on one GPU (different streams)
+ * race on it; calls on one stream are ordered and safe.  Nothing in it needs clearing between calls
+ * (every partial row is written by its piece before the merge pass reads it).
+ * ---------------------------------------------------------------------- */
+#define TMX_STATIC_WORKSPACE_BYTES (32u << 20)
+size_t tmx_static_workspace_bytes(void);
+int tmx_attention_static_ws(const tmx_attention_args_t* args, void* stream);
 
 /* ------------------------------------------------------------------------
  * K/V cache write: copies key/value rows of this step into the paged cache,

@@ -508,8 +508,8 @@ def fp8_e4m3fn_encode(x: np.ndarray) -> np.ndarray:
 def fp8_cache_roundtrip(x: np.ndarray, scale: float = 1.0) -> np.ndarray:
     """What the attention sees of a value written to an fp8 cache: fp8(x / scale) * scale (float64;
     the 16-bit rounding of the descaled value is the caller's, see :func:`bf16_round`)."""
-    inv = np.float32(1.0) / np.float32(scale)  # the write multiplies by the reciprocal, in fp32
-    q = fp8_e4m3fn_encode((np.asarray(x, np.float32) * inv).astype(np.float32))
+    # the write divides in fp32, as the reference's scaled conversion does (quant_utils.cuh:544,589: a / scale)
+    q = fp8_e4m3fn_encode((np.asarray(x, np.float32) / np.float32(scale)).astype(np.float32))
     return (fp8_e4m3fn_decode(q).astype(np.float32) * np.float32(scale)).astype(np.float64)
 
 

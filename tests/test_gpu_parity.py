@@ -935,9 +935,9 @@ def test_fp8_kv_cache_write_gather_and_backend():
     torch.cuda.synchronize()
     flat_k = kv_cache[0].view(nblk * page, Hkv, D).cpu().numpy()
     flat_v = kv_cache[1].view(nblk * page, Hkv, D).cpu().numpy()
-    inv_k, inv_v = np.float32(1.0) / np.float32(k_scale), np.float32(1.0) / np.float32(v_scale)
-    want_k = orc.fp8_e4m3fn_encode(ck.float().cpu().numpy() * inv_k)
-    want_v = orc.fp8_e4m3fn_encode(cv.float().cpu().numpy() * inv_v)
+    # the write divides by the scale in fp32 (quant_utils.cuh:544,589), it does not multiply by a reciprocal
+    want_k = orc.fp8_e4m3fn_encode(ck.float().cpu().numpy() / np.float32(k_scale))
+    want_v = orc.fp8_e4m3fn_encode(cv.float().cpu().numpy() / np.float32(v_scale))
     assert np.array_equal(flat_k[cs], want_k) and np.array_equal(flat_v[cs], want_v)
     untouched = np.ones(nblk * page, bool)
     untouched[cs] = False
@@ -1046,3 +1046,63 @@ def test_torch_library_binding_equals_ctypes_path():
     with pytest.raises(RuntimeError, match="trianglemix"):
         C.trianglemix_attention(out_t, qd, kc, vc, btd, cu, sld, None, index, tile_pages, part_o, part_ml, None,
                                 -1.0, si, sl, last, mode, 0, chunk, n_items, n_part, n_split)
+
+
+def test_backend_length_gate_2048_vs_2049(golden_attention):
+    """The reference gives no mask up to 2048 tokens and the triangle mask from 2049 on
+    (trianglemix_attention.py:330-332).  Through the backend: a 2048-token prompt runs plain causal attention,
+    a 2049-token prompt the triangle pattern; both in one step, checked against the oracle, and the 2049 case
+    also against the reference's own output (golden ``helper_tri_2049``: one head, head size 64)."""
+    import types
+    from vllm_trianglemix_amd import TriangleMixConfig
+    from vllm_trianglemix_amd.backend import TriangleMixAttentionBackend
+    meta, arrays = golden_attention
+    (g,) = [c for c in meta["cases"] if c["name"] == "helper_tri_2049"]
+    H, Hkv, D, page = 1, 1, 64, 16
+    qg, kg, vg = (orc.seeded_normal(g["seed"] * 3 + t, (1, 2049, 1, 64))[0] for t in range(3))
+    q_lens = seq_lens = [2048, 2049]
+    q, ks, vs = _rand_case(77, q_lens, seq_lens, H, Hkv, D)
+    q[2048:], ks[1], vs[1] = qg, kg, vg
+    scale = float(g["scale"])
+    cu = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    T = int(cu[-1])
+    nblk = sum((s + page - 1) // page for s in seq_lens) + 2
+    perm = np.random.default_rng(5).permutation(nblk).astype(np.int32)
+    bt = np.zeros((2, (2049 + page - 1) // page), np.int32)
+    slots = np.zeros((T,), np.int64)
+    nxt = 0
+    for b, s in enumerate(seq_lens):
+        for pb in range((s + page - 1) // page):
+            bt[b, pb] = perm[nxt]
+            nxt += 1
+        pos = np.arange(s)
+        slots[cu[b]:cu[b + 1]] = bt[b, pos // page].astype(np.int64) * page + pos % page
+    common = types.SimpleNamespace(
+        num_actual_tokens=T, max_query_len=2049, max_seq_len=2049,
+        query_start_loc=torch.from_numpy(cu).to(DEV), query_start_loc_cpu=torch.from_numpy(cu),
+        seq_lens=torch.tensor(seq_lens, dtype=torch.int32, device=DEV), seq_lens_cpu=torch.tensor(seq_lens, dtype=torch.int32),
+        block_table_tensor=torch.from_numpy(bt).to(DEV), slot_mapping=torch.from_numpy(slots).to(DEV))
+    md = TriangleMixAttentionBackend.get_builder_cls()(types.SimpleNamespace(block_size=page), ["l0"], None,
+                                                       torch.device(DEV)).build(0, common)
+    impl = TriangleMixAttentionBackend.get_impl_cls()(H, D, scale, Hkv, None, None, "auto", None, "decoder", None,
+                                                      trianglemix_config=TriangleMixConfig(num_triangle_layers=1),
+                                                      layer_idx=0)
+    assert impl.tri_min_len == 2048
+    kv_cache = torch.zeros(TriangleMixAttentionBackend.get_kv_cache_shape(nblk, page, Hkv, D), dtype=torch.bfloat16,
+                           device=DEV)
+    out = torch.zeros((T, H * D), dtype=torch.float32, device=DEV)
+    impl.forward(None, _to_dev(q, torch.bfloat16), _to_dev(np.concatenate(ks), torch.bfloat16),
+                 _to_dev(np.concatenate(vs), torch.bfloat16), kv_cache, md, output=out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(T, H, D)
+    for b, (s, mode) in enumerate(zip(seq_lens, ("causal", "triangle"))):
+        ref = orc.varlen_gqa_attention(q[cu[b]:cu[b + 1]], lambda _: ks[b], lambda _: vs[b], [0, s], [s], scale, mode,
+                                       4, 32, 64)
+        assert float(np.abs(got[cu[b]:cu[b + 1]] - ref).max()) <= ATOL_F32_OUT, (s, mode)
+    # 2049 tokens: causal attention would differ visibly from the triangle pattern on the middle rows
+    dense = orc.varlen_gqa_attention(q[2048:], lambda _: ks[1], lambda _: vs[1], [0, 2049], [2049], scale, "causal",
+                                     0, 0, 0)
+    assert float(np.abs(got[2048:] - dense).max()) > 0.05
+    # the reference's own fp32 run on the same (bf16-representable) inputs
+    want = arrays["helper_tri_2049"][0]
+    assert float(np.abs(got[2048:] - want).max()) <= ATOL_F32_OUT

@@ -1,0 +1,71 @@
+"""The entry point that allocates nothing (tmx_attention_static_ws): same results, bit for bit, as
+tmx_attention with a caller-provided work area; two calls in a row on one GPU, the second smaller."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import trianglemix_oracle as orc
+from vllm_trianglemix_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _case(seed, q_lens, seq_lens, H, Hkv, D, chunk):
+    rng = np.random.default_rng(seed)
+    T, rows = int(sum(q_lens)), int(sum(seq_lens))
+    q = torch.from_numpy(rng.standard_normal((T, H, D), dtype=np.float32)).to(DEV).bfloat16()
+    k = torch.from_numpy(rng.standard_normal((rows, Hkv, D), dtype=np.float32)).to(DEV).bfloat16()
+    v = torch.from_numpy(rng.standard_normal((rows, Hkv, D), dtype=np.float32)).to(DEV).bfloat16()
+    cu_h = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    sl_h = np.asarray(seq_lens, np.int32)
+    cuk_h = np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)
+    cu, sld, cuk = (torch.from_numpy(x).to(DEV) for x in (cu_h, sl_h, cuk_h))
+    bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
+    idx = ops.build_block_index(cu, sld, cu_h, sl_h, 4, 32, 64, bm, bn, ops.MODES["triangle"], chunk_tiles=chunk)
+    return q, k, v, idx, cu, sld, cuk, cu_h, cuk_h
+
+
+def _run(case, static_workspace):
+    q, k, v, idx, cu, sld, cuk, _, _ = case
+    out = torch.full(q.shape, float("nan"), dtype=torch.float32, device=DEV)
+    ops.attention(q, k, v, out, idx, cu, sld, q.shape[-1] ** -0.5, cu_seqlens_k=cuk, static_workspace=static_workspace)
+    return out
+
+
+def test_static_workspace_entry_point_matches_the_allocating_one():
+    assert _lib.load().tmx_static_workspace_bytes() == 32 << 20
+    H, Hkv, D = 8, 2, 128
+    # first call: two long prompts + a decode row over a long context, many pieces (chunk 4);
+    # second call, straight after on the same stream: a smaller step (fewer, other pieces)
+    big = _case(1, [3000, 1, 2500], [3000, 2700, 2500], H, Hkv, D, chunk=4)
+    small = _case(2, [700, 1], [700, 900], H, Hkv, D, chunk=8)
+    assert big[3].sizes.num_partials > small[3].sizes.num_partials > 0
+    before = torch.cuda.memory_allocated()
+    got_big = _run(big, True)
+    got_small = _run(small, True)
+    # (the two output tensors above are the test's own; the entry point itself took nothing from the allocator)
+    assert torch.cuda.memory_allocated() - before == got_big.numel() * 4 + got_small.numel() * 4
+    want_big, want_small = _run(big, False), _run(small, False)
+    torch.cuda.synchronize()
+    assert torch.equal(got_big, want_big) and torch.equal(got_small, want_small)
+    assert not torch.isnan(got_big).any() and not torch.isnan(got_small).any()
+    # and against the oracle, to the bar of the other parity tests
+    q, k, v, idx, cu, sld, cuk, cu_h, cuk_h = small
+    kf, vf = k.float().cpu().numpy(), v.float().cpu().numpy()
+    ref = orc.varlen_gqa_attention(q.float().cpu().numpy(), lambda b: kf[cuk_h[b]:cuk_h[b + 1]],
+                                   lambda b: vf[cuk_h[b]:cuk_h[b + 1]], cu_h, [700, 900], D ** -0.5, "triangle",
+                                   4, 32, 64)
+    assert float(np.abs(got_small.cpu().numpy() - ref).max()) <= 1e-3
+
+
+def test_static_workspace_rejects_steps_beyond_its_size():
+    H, Hkv, D = 32, 8, 128
+    # 40 pieces x 32 heads x 32 rows x 130 floats = 21 MB fits; chunk 1 on a 3000-token strip does not
+    q_lens = seq_lens = [3000]
+    case = _case(3, q_lens, seq_lens, H, Hkv, D, chunk=1)
+    need = int(case[3].sizes.num_partials) * H * 32 * (D + 2) * 4
+    assert need > (32 << 20)
+    with pytest.raises(_lib.TmxError) as e:
+        _run(case, True)
+    assert e.value.code == _lib.TMX_ERR_CAPACITY and "work area" in str(e.value)

@@ -14,13 +14,14 @@ TMX_OK, TMX_ERR_INVALID_ARG, TMX_ERR_UNSUPPORTED, TMX_ERR_HIP, TMX_ERR_CAPACITY 
 TMX_F32, TMX_BF16, TMX_F16, TMX_FP8_E4M3 = range(4)
 TMX_MODE_NONE, TMX_MODE_CAUSAL, TMX_MODE_TRIANGLE = range(3)
 TMX_MASK_STREAMING, TMX_MASK_LAST, TMX_MASK_MIDDLE, TMX_MASK_TRIANGLE, TMX_MASK_DENSE = range(5)
-TMX_ABI_VERSION = 2
+TMX_ABI_VERSION = 3
 
 # every symbol include/trianglemix_hip.h declares
 EXPORTED_SYMBOLS = (
     "tmx_abi_version", "tmx_last_error", "tmx_attention_block_m", "tmx_attention_block_n", "tmx_dense_mask",
     "tmx_replace_neg_inf", "tmx_index_sizes", "tmx_build_block_index", "tmx_attention", "tmx_reshape_and_cache",
     "tmx_reshape_and_cache_fp8", "tmx_gather_dequant_kv_fp8", "tmx_suggest_chunk_tiles",
+    "tmx_attention_static_ws", "tmx_static_workspace_bytes",
 )
 
 
@@ -64,6 +65,7 @@ class AttentionArgs(Structure):
         ("bias_rows", c_int32), ("bias_cols", c_int32),
         ("index", POINTER(Index)),
         ("num_items", c_int64), ("num_partials", c_int64), ("num_split_qblocks", c_int64),
+        ("nnz_tiles", c_int64),
         ("partial_o", c_void_p), ("partial_ml", c_void_p),
         ("flags", c_uint32), ("reserved", c_uint32),
     ]
@@ -97,6 +99,9 @@ def load() -> ctypes.CDLL:
                                             c_int, c_int, c_int, c_int, POINTER(c_int)]
     lib.tmx_build_block_index.argtypes = [POINTER(Index), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.tmx_attention.argtypes = [POINTER(AttentionArgs), c_void_p]
+    lib.tmx_attention_static_ws.argtypes = [POINTER(AttentionArgs), c_void_p]
+    lib.tmx_static_workspace_bytes.argtypes = []
+    lib.tmx_static_workspace_bytes.restype = ctypes.c_size_t
     lib.tmx_reshape_and_cache.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                           c_int64, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p]

@@ -30,6 +30,7 @@
 // products, and every lane ends with 8 consecutive output columns per store.
 #include "tmx_common.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1019,15 +1020,33 @@ constexpr int kRingSlots = 3;  // K/V ring entries of the attention kernel (plus
 
 // Persistent grid: as many workgroups as stay resident (LDS and registers allow a fixed number per
 // CU), rounded down to a multiple of the units per item so that a workgroup keeps one K/V head.
+// The resident count of an instantiation is asked of the runtime once per device and kept.
+constexpr int kMaxDevices = 64;
+
 template <typename K>
-static int persistent_grid(K kernel, const AttnParams& p, unsigned* grid_out) {
-  int dev = 0, cus = 0, per_cu = 0;
+static int resident_workgroups(K kernel, unsigned* cache, long long* out) {
+  int dev = 0;
   TMX_CHECK_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < kMaxDevices && cache[dev] != 0) {
+    *out = cache[dev];
+    return TMX_OK;
+  }
+  int cus = 0, per_cu = 0;
   TMX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   TMX_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * kWaves, 0));
   if (per_cu < 1) per_cu = 1;
-  long long w = (long long)cus * per_cu;
-  if (w > p.units_total) w = p.units_total;
+  *out = (long long)cus * per_cu;
+  if (dev >= 0 && dev < kMaxDevices) cache[dev] = (unsigned)*out;  // same value from every thread
+  return TMX_OK;
+}
+
+// Grid of the persistent kernel for `resident` workgroup slots: every workgroup keeps ONE of the Y
+// (K/V head, head chunk) units, so the grid is a multiple of Y, or exactly the work there is.
+static int persistent_grid(long long resident, const AttnParams& p, unsigned* grid_out) {
+  long long w = resident < p.units_total ? resident : p.units_total;
+  TMX_CHECK_SUPPORTED(w >= p.Y || w == p.units_total,
+                      "tmx_attention: %d K/V head chunks need at least as many resident workgroups (%lld)", p.Y,
+                      resident);
   if (w > p.Y) w -= w % p.Y;
   *grid_out = (unsigned)w;
   return TMX_OK;
@@ -1036,13 +1055,13 @@ static int persistent_grid(K kernel, const AttnParams& p, unsigned* grid_out) {
 template <typename TR, int D, bool PAGED, bool HAS_BIAS>
 static int launch_attn(const AttnParams& p, hipStream_t s) {
   auto kernel = attn_kernel<TR, D, kRingSlots, PAGED, HAS_BIAS>;
-  static unsigned cached_grid_cap[16] = {0};  // per device: resident workgroups of this instantiation
-  int dev = 0;
-  TMX_CHECK_HIP(hipGetDevice(&dev));
-  unsigned grid = 0;
-  int rc = persistent_grid(kernel, p, &grid);
+  static unsigned resident_cache[kMaxDevices] = {0};  // per device: resident workgroups of this instantiation
+  long long resident = 0;
+  int rc = resident_workgroups(kernel, resident_cache, &resident);
   if (rc != TMX_OK) return rc;
-  (void)cached_grid_cap;
+  unsigned grid = 0;
+  rc = persistent_grid(resident, p, &grid);
+  if (rc != TMX_OK) return rc;
   kernel<<<grid, 64 * kWaves, 0, s>>>(p);
   TMX_CHECK_HIP(hipGetLastError());
   return TMX_OK;
@@ -1068,13 +1087,17 @@ static int launch(const AttnParams& p, bool paged, bool has_bias, int64_t num_sp
 // of a split q-block does.  A piece is chunk_tiles arithmetic-bound tile steps; a light item costs its tile
 // steps plus a fixed part (query rows in, output rows out, set-up) worth about six steps when it runs beside
 // a piece (measured on MI355X: 64-tile pieces against 3-tile items balance at 6..8 items per piece).
-// TMX_SCHED_W overrides it (tuning runs).
+// TMX_SCHED_W overrides it in diagnostic builds (tuning runs).
 static int sched_light_per_piece(const tmx_attention_args_t* a, const tmx_index_t* ix) {
+#ifdef TMX_STAMPS
   static const char* env = getenv("TMX_SCHED_W");
   if (env != nullptr) return atoi(env);
+#endif
   const long long pieces = a->num_partials, light = a->num_items - a->num_partials;
   if (pieces <= 0 || light <= 0) return 0;
-  const long long light_tiles = ix->cap_nnz - pieces * ix->chunk_tiles;  // lower bound: last pieces are shorter
+  // listed tiles: the count the caller passes (tmx_index_sizes), else the buffer's capacity as an upper bound
+  const long long nnz = a->nnz_tiles > 0 ? a->nnz_tiles : ix->cap_nnz;
+  const long long light_tiles = nnz - pieces * ix->chunk_tiles;  // lower bound: last pieces are shorter
   const double avg = light_tiles > light ? (double)light_tiles / (double)light : 1.0;
   const double w = (double)ix->chunk_tiles / (6.0 + avg);
   return w > 64.0 ? 64 : (int)(w + 0.5);
@@ -1217,4 +1240,65 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   }
   if (a->head_dim == 128) return launch<F16Traits, 128>(p, paged, has_bias, a->num_split_qblocks, a->flags, s);
   return launch<F16Traits, 64>(p, paged, has_bias, a->num_split_qblocks, a->flags, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same call for callers that may not allocate: the work area of the split q-blocks lives in the
+// library's own device memory.  Every device the library runs on holds one copy of the array (at its own
+// address) until the process ends.
+namespace tmx {
+
+constexpr size_t kStaticWsBytes = (size_t)TMX_STATIC_WORKSPACE_BYTES;
+static __device__ __align__(256) unsigned char static_ws[kStaticWsBytes];
+
+// Device address of this device's copy of static_ws.  The array's name is only a handle on the host:
+// the address comes from hipGetSymbolAddress, asked once per device with that device current.
+static int static_ws_base(unsigned char** out) {
+  static std::atomic<unsigned char*> base[kMaxDevices];
+  int dev = 0;
+  TMX_CHECK_HIP(hipGetDevice(&dev));
+  TMX_CHECK_SUPPORTED(dev >= 0 && dev < kMaxDevices, "tmx_attention_static_ws: device ordinal %d out of range", dev);
+  unsigned char* ptr = base[dev].load(std::memory_order_acquire);
+  if (ptr == nullptr) {
+    TMX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(static_ws)));
+    TMX_CHECK_ARG(ptr != nullptr, "tmx_attention_static_ws: no device address for the static work area");
+    base[dev].store(ptr, std::memory_order_release);  // every thread gets the same answer for a device
+  }
+  *out = ptr;
+  return TMX_OK;
+}
+
+}  // namespace tmx
+
+extern "C" size_t tmx_static_workspace_bytes(void) { return tmx::kStaticWsBytes; }
+
+extern "C" int tmx_attention_static_ws(const tmx_attention_args_t* a, void* stream) {
+  using namespace tmx;
+  TMX_CHECK_ARG(a != nullptr, "tmx_attention_static_ws: args is NULL");
+  TMX_CHECK_ARG(a->struct_size == sizeof(tmx_attention_args_t),
+                "tmx_attention_static_ws: struct_size %u != %zu (ABI mismatch)", a->struct_size,
+                sizeof(tmx_attention_args_t));
+  tmx_attention_args_t b = *a;
+  b.partial_o = nullptr;
+  b.partial_ml = nullptr;
+  if (a->num_partials > 0) {
+    TMX_CHECK_ARG(a->index != nullptr && a->num_heads > 0 && a->head_dim > 0 && a->index->block_m > 0,
+                  "tmx_attention_static_ws: bad sizes");
+    // partial_o [P][H][block_m][D] floats, then partial_ml [P][H][block_m][2] floats on the next 256-byte boundary
+    const unsigned long long rows = (unsigned long long)a->num_partials * (unsigned long long)a->num_heads *
+                                    (unsigned long long)a->index->block_m;
+    const unsigned long long o_bytes = (rows * (unsigned long long)a->head_dim * 4ull + 255ull) & ~255ull;
+    const unsigned long long need = o_bytes + rows * 8ull;
+    if (rows > (1ull << 40) || need > kStaticWsBytes) {
+      set_error("tmx_attention_static_ws: the split q-blocks of this step need %llu bytes of work area, the library "
+                "holds %zu (use tmx_attention with a workspace of your own, or longer pieces)", need, kStaticWsBytes);
+      return TMX_ERR_CAPACITY;
+    }
+    unsigned char* base = nullptr;
+    const int rc = static_ws_base(&base);
+    if (rc != TMX_OK) return rc;
+    b.partial_o = reinterpret_cast<float*>(base);
+    b.partial_ml = reinterpret_cast<float*>(base + o_bytes);
+  }
+  return tmx_attention(&b, stream);
 }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_fp8_kernel(
     const uint16_t* __restrict__ key, const uint16_t* __restrict__ value, int64_t in_stride_t, int64_t in_stride_h,
     uint8_t* __restrict__ key_cache, uint8_t* __restrict__ value_cache, int64_t stride_page, int64_t stride_t,
     int64_t stride_h, const int64_t* __restrict__ slot_mapping, int num_kv_heads, int head_dim, int page_size,
-    int in_dtype, float k_inv_scale, float v_inv_scale) {
+    int in_dtype, float k_scale, float v_scale) {
   const int t = blockIdx.x;
   const int64_t slot = slot_mapping[t];
   if (slot < 0) return;
@@ -105,14 +105,14 @@ __global__ __launch_bounds__(256) void reshape_and_cache_fp8_kernel(
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
       int a = 0, b = 0;
-      a = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(kp + 4 * w, in_dtype) * k_inv_scale),
-                                          sat448(load16(kp + 4 * w + 1, in_dtype) * k_inv_scale), a, false);
-      a = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(kp + 4 * w + 2, in_dtype) * k_inv_scale),
-                                          sat448(load16(kp + 4 * w + 3, in_dtype) * k_inv_scale), a, true);
-      b = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(vp + 4 * w, in_dtype) * v_inv_scale),
-                                          sat448(load16(vp + 4 * w + 1, in_dtype) * v_inv_scale), b, false);
-      b = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(vp + 4 * w + 2, in_dtype) * v_inv_scale),
-                                          sat448(load16(vp + 4 * w + 3, in_dtype) * v_inv_scale), b, true);
+      a = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(kp + 4 * w, in_dtype) / k_scale),
+                                          sat448(load16(kp + 4 * w + 1, in_dtype) / k_scale), a, false);
+      a = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(kp + 4 * w + 2, in_dtype) / k_scale),
+                                          sat448(load16(kp + 4 * w + 3, in_dtype) / k_scale), a, true);
+      b = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(vp + 4 * w, in_dtype) / v_scale),
+                                          sat448(load16(vp + 4 * w + 1, in_dtype) / v_scale), b, false);
+      b = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(vp + 4 * w + 2, in_dtype) / v_scale),
+                                          sat448(load16(vp + 4 * w + 3, in_dtype) / v_scale), b, true);
       kw[w] = (uint32_t)a;
       vw[w] = (uint32_t)b;
     }
@@ -204,7 +204,7 @@ extern "C" int tmx_reshape_and_cache_fp8(const void* key, const void* value, int
   tmx::reshape_and_cache_fp8_kernel<<<num_tokens, threads, 0, (hipStream_t)stream>>>(
       (const uint16_t*)key, (const uint16_t*)value, in_stride_t, in_stride_h, (uint8_t*)key_cache,
       (uint8_t*)value_cache, stride_page, stride_t, stride_h, slot_mapping, num_kv_heads, head_dim, page_size,
-      in_dtype, 1.0f / k_scale, 1.0f / v_scale);
+      in_dtype, k_scale, v_scale);
   TMX_CHECK_HIP(hipGetLastError());
   return TMX_OK;
 }

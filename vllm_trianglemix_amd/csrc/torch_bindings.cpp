@@ -128,7 +128,7 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
                const std::optional<Tensor>& partial_ml, const std::optional<Tensor>& bias, double scale, int64_t si,
                int64_t sl, int64_t last, int64_t mode, int64_t tri_min_len, int64_t chunk_tiles, int64_t num_items,
                int64_t num_partials, int64_t num_split_qblocks, const std::optional<Tensor>& full_lens,
-               int64_t flags) {
+               int64_t flags, int64_t nnz_tiles) {
   const DeviceGuard guard(query.device());
   TORCH_CHECK(query.dim() == 3 && out.dim() == 3, "trianglemix: query / out must be [T, H, D]");
   const bool paged = block_table.has_value();
@@ -186,6 +186,7 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
   a.num_items = num_items;
   a.num_partials = num_partials;
   a.num_split_qblocks = num_split_qblocks;
+  a.nnz_tiles = nnz_tiles;  // 0: unknown (the library then falls back to the capacity of col_idx)
   a.partial_o = partial_o.has_value() ? partial_o->data_ptr<float>() : nullptr;
   a.partial_ml = partial_ml.has_value() ? partial_ml->data_ptr<float>() : nullptr;
   a.flags = (uint32_t)flags;
@@ -256,7 +257,7 @@ TORCH_LIBRARY(_trianglemix_C, m) {
         "Tensor cu_seqlens_q, Tensor seq_lens, Tensor? cu_seqlens_k, Tensor[] index, Tensor? tile_pages, "
         "Tensor? partial_o, Tensor? partial_ml, Tensor? bias, float scale, int si, int sl, int last, int mode, "
         "int tri_min_len, int chunk_tiles, int num_items, int num_partials, int num_split_qblocks, "
-        "Tensor? full_lens=None, int flags=0) -> ()");
+        "Tensor? full_lens=None, int flags=0, int nnz_tiles=0) -> ()");
   m.impl("trianglemix_attention", c10::DispatchKey::CUDA, &attention);
   m.def("trianglemix_reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, "
         "Tensor slot_mapping) -> ()");

@@ -256,8 +256,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
               cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, scale: float,
               cu_seqlens_k: Optional[torch.Tensor] = None, block_table: Optional[torch.Tensor] = None,
               bias: Optional[torch.Tensor] = None, workspace: Optional[Sequence[torch.Tensor]] = None,
-              flags: int = 0) -> torch.Tensor:
+              flags: int = 0, static_workspace: bool = False) -> torch.Tensor:
     """Masked attention over the tiles ``index`` lists.
+
+    ``static_workspace``: call ``tmx_attention_static_ws`` -- the partial results of split q-blocks go
+    to the library's fixed device array instead of ``workspace`` (nothing is allocated; steps that need
+    more than ``tmx_static_workspace_bytes()`` raise).
 
     ``q``/``out``: ``[T, H, D]`` (last dim contiguous).  Contiguous K/V:
     ``k``/``v`` ``[rows, Hkv, D]`` + ``cu_seqlens_k``.  Paged K/V: ``k``/``v``
@@ -317,19 +321,24 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     a.index = ctypes.pointer(index.c)
     sz = index.sizes
     a.num_items, a.num_partials, a.num_split_qblocks = sz.num_items, sz.num_partials, sz.num_split_qblocks
+    a.nnz_tiles = sz.nnz_tiles
     part_o = part_ml = None
-    if workspace is not None:
+    if static_workspace:
+        pass
+    elif workspace is not None:
         part_o, part_ml = workspace
     elif sz.num_partials > 0:
         part_o, part_ml = alloc_workspace(index, H, D, q.device)
-    if sz.num_partials > 0:
+    if sz.num_partials > 0 and not static_workspace:
         need = int(sz.num_partials) * H * index.block_m
         if part_o.numel() < need * D or part_ml.numel() < need * 2 or part_o.dtype != torch.float32:
             raise RuntimeError("attention workspace too small for this index")
     a.partial_o, a.partial_ml = _ptr(part_o), _ptr(part_ml)
     a.flags, a.reserved = int(flags), 0
     with torch.cuda.device(q.device):
-        check(_lib.load().tmx_attention(ctypes.byref(a), _stream(q.device)))
+        lib = _lib.load()
+        entry = lib.tmx_attention_static_ws if static_workspace else lib.tmx_attention
+        check(entry(ctypes.byref(a), _stream(q.device)))
     return out
 
 
