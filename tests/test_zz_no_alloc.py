@@ -26,9 +26,11 @@ def _case(seed, q_lens, seq_lens, H, Hkv, D, chunk):
     return q, k, v, idx, cu, sld, cuk, cu_h, cuk_h
 
 
-def _run(case, static_workspace):
+def _run(case, static_workspace, out=None):
     q, k, v, idx, cu, sld, cuk, _, _ = case
-    out = torch.full(q.shape, float("nan"), dtype=torch.float32, device=DEV)
+    if out is None:
+        out = torch.empty(q.shape, dtype=torch.float32, device=DEV)
+    out.fill_(float("nan"))
     ops.attention(q, k, v, out, idx, cu, sld, q.shape[-1] ** -0.5, cu_seqlens_k=cuk, static_workspace=static_workspace)
     return out
 
@@ -41,11 +43,16 @@ def test_static_workspace_entry_point_matches_the_allocating_one():
     big = _case(1, [3000, 1, 2500], [3000, 2700, 2500], H, Hkv, D, chunk=4)
     small = _case(2, [700, 1], [700, 900], H, Hkv, D, chunk=8)
     assert big[3].sizes.num_partials > small[3].sizes.num_partials > 0
-    before = torch.cuda.memory_allocated()
-    got_big = _run(big, True)
-    got_small = _run(small, True)
-    # (the two output tensors above are the test's own; the entry point itself took nothing from the allocator)
-    assert torch.cuda.memory_allocated() - before == got_big.numel() * 4 + got_small.numel() * 4
+    got_big = torch.empty(big[0].shape, dtype=torch.float32, device=DEV)
+    got_small = torch.empty(small[0].shape, dtype=torch.float32, device=DEV)
+    torch.cuda.synchronize()
+    stats = torch.cuda.memory_stats()
+    before = (torch.cuda.memory_allocated(), stats["allocation.all.allocated"])
+    _run(big, True, got_big)
+    _run(small, True, got_small)
+    # the calls took nothing from torch's allocator either (outputs are the test's own, made above)
+    stats = torch.cuda.memory_stats()
+    assert (torch.cuda.memory_allocated(), stats["allocation.all.allocated"]) == before
     want_big, want_small = _run(big, False), _run(small, False)
     torch.cuda.synchronize()
     assert torch.equal(got_big, want_big) and torch.equal(got_small, want_small)
