@@ -7,12 +7,20 @@ the packed block-sparse index is built on the device and the masked
 (prefill, paged K/V cache, page size 16, shuffled block table).
 
 N = 1: one 32768-token prompt, 32 query heads / 8 K/V heads / head dim 128.
-N > 1 (launched by torch.distributed.run, one rank per GPU): head-parallel
-tensor parallelism -- rank r owns 32/N query heads and 8/N K/V heads -- with
-the global batch grown to N prompts, so each rank keeps the same number of
-(prompt, head) units (weak scaling).  The attention needs no collective; the
-output projection's all-reduce (the only exchange step of the layer) is timed
-separately with --oproj and reported beside the main value, never inside it.
+N > 1: one rank per GPU, head-parallel tensor parallelism -- rank r owns H/N
+query heads and Hkv/N K/V heads -- with the global batch grown to N prompts,
+so each rank keeps the same number of (prompt, head) units (weak scaling).
+The ranks come either from torch.distributed.run (RANK / WORLD_SIZE in the
+environment) or, when `--gpus N` is given without them, from this script
+itself: it starts N copies of itself BEFORE touching any GPU, relays rank 0's
+line and exits non-zero unless all N ranks finish.  The attention needs no
+collective; the output projection's all-reduce (the only exchange step of the
+layer) is timed separately with --oproj and reported beside the main value,
+never inside it.
+
+--model picks the head shape: 8b (32/8 heads, 32k), 32b (64/8 heads, 32k: 16/2
+per GPU at --gpus 4), 72b-fp8 (64/8 heads, fp8 e4m3 K/V cache, 64k: 8/1 per GPU
+at --gpus 8).
 
 Prints ONE JSON line (rank 0).
 """
@@ -21,6 +29,8 @@ import ctypes
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +44,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (no sparsity)
 QWEN3_8B = dict(num_heads=32, num_kv_heads=8, head_dim=128, hidden=4096)
+# head shapes of the benchmark configurations (the 72B row is the 64-head / 8-K/V-head shape with hidden 8192;
+# there is no such Qwen3 release, the shape is what matters to the attention)
+MODELS = {
+    "8b": dict(name="Qwen3-8B", num_heads=32, num_kv_heads=8, head_dim=128, hidden=4096, seq_len=32768, kv="bf16"),
+    "32b": dict(name="Qwen3-32B", num_heads=64, num_kv_heads=8, head_dim=128, hidden=5120, seq_len=32768, kv="bf16"),
+    "72b-fp8": dict(name="Qwen3-72B-shape", num_heads=64, num_kv_heads=8, head_dim=128, hidden=8192, seq_len=65536,
+                    kv="fp8"),
+}
 PATTERN = (4, 32, 64)  # sink, window, last: the reference defaults
 PAGE = 16
 
@@ -46,7 +64,11 @@ def parse():
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed steps run for this long before the warm-up steps: an idle GPU needs tens of "
                          "milliseconds of load before its clocks settle (0.25 ms steps: 10 warm-up steps are 2.5 ms)")
-    ap.add_argument("--seq-len", type=int, default=32768)
+    ap.add_argument("--model", choices=sorted(MODELS), default="8b", help="head shape and K/V cache type")
+    ap.add_argument("--seq-len", type=int, default=0, help="prompt length (0: the model's configuration)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the ranks rendezvous over gloo, size their shard of the job on the host and print "
+                         "the line without a measurement (checks the launcher and the sharding arithmetic)")
     ap.add_argument("--oproj", action="store_true", help="also time o_proj GEMM + all-reduce (reported separately)")
     ap.add_argument("--no-baselines", action="store_true", help="skip the dense and CPU baselines")
     ap.add_argument("--cpu-rows", type=int, default=4096, help="query rows of the CPU-baseline sample")
@@ -58,8 +80,9 @@ def parse():
     return ap.parse_args()
 
 
-def make_inputs(ops, dev, n, batch, heads, kv_heads, dim, seed):
-    """q [batch*n, heads, dim] bf16, paged K/V cache filled through the cache-write kernel."""
+def make_inputs(ops, dev, n, batch, heads, kv_heads, dim, seed, fp8=False):
+    """q [batch*n, heads, dim] bf16, paged K/V cache (bf16, or fp8 e4m3 with unit scales) filled through the
+    cache-write kernel."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     T = batch * n
     q = torch.randn((T, heads, dim), generator=g, dtype=torch.float32).to(dev).bfloat16()
@@ -71,8 +94,12 @@ def make_inputs(ops, dev, n, batch, heads, kv_heads, dim, seed):
     block_table = perm.view(batch, pages_per_seq).contiguous()
     pos = torch.arange(n, dtype=torch.int64)
     slots = torch.cat([block_table[b].to(torch.int64)[pos // PAGE] * PAGE + pos % PAGE for b in range(batch)])
-    kv_cache = torch.zeros((2, nblk, PAGE, kv_heads, dim), dtype=torch.bfloat16, device=dev)
-    ops.reshape_and_cache(k, v, kv_cache[0], kv_cache[1], slots.to(dev))
+    if fp8:
+        kv_cache = torch.zeros((2, nblk, PAGE, kv_heads, dim), dtype=torch.uint8, device=dev)
+        ops.reshape_and_cache_fp8(k, v, kv_cache[0], kv_cache[1], slots.to(dev), 1.0, 1.0)
+    else:
+        kv_cache = torch.zeros((2, nblk, PAGE, kv_heads, dim), dtype=torch.bfloat16, device=dev)
+        ops.reshape_and_cache(k, v, kv_cache[0], kv_cache[1], slots.to(dev))
     cu_h = (np.arange(batch + 1) * n).astype(np.int32)
     sl_h = np.full((batch,), n, np.int32)
     return dict(q=q, k=k, v=v, kv_cache=kv_cache, block_table=block_table.to(dev), cu_h=cu_h, sl_h=sl_h,
@@ -126,17 +153,113 @@ def cpu_baseline(n, heads, dim, rows, sample_heads):
                       f"all rows and heads"}
 
 
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`--gpus N` without a launcher: start N copies of this script, one rank per GPU, BEFORE anything here
+    has touched a GPU (this process never does: it only relays rank 0's line).  Returns the exit code:
+    non-zero unless all N ranks ran to the end and rank 0 printed a line for N GPUs."""
+    n = args.gpus
+    if not args.dry_run and torch.cuda.device_count() < n:  # counting devices does not initialise them
+        print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} HIP device(s) are visible", file=sys.stderr)
+        return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.2)
+    if failed is None:
+        failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:  # the exact processes started above, nothing else
+            if p.poll() is None:
+                p.kill()
+        print(f"bench.py: rank {failed} of {n} exited with {procs[failed].returncode}; no result", file=sys.stderr)
+        return 1
+    out = procs[0].stdout.read()
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if not lines or json.loads(lines[-1]).get("n_gpus") != n:
+        print(f"bench.py: rank 0 printed no line for {n} GPUs", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def dry_run(args, cfg, n, world, rank):
+    """No GPU: rendezvous over gloo, every rank sizes its shard of the job on the host (head shard, index sizes,
+    piece length), the ranks agree on the maximum, rank 0 prints the line without a measurement."""
+    import torch.distributed as dist
+    from vllm_trianglemix_amd import ops
+    from vllm_trianglemix_amd.parallel import shard_heads
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = shard_heads(cfg["num_heads"], cfg["num_kv_heads"], rank, world)
+    H, Hkv = shard.num_heads, shard.num_kv_heads
+    batch = world
+    cu_h, sl_h = (np.arange(batch + 1) * n).astype(np.int32), np.full((batch,), n, np.int32)
+    bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
+    chunk = ops.suggest_chunk_tiles(cu_h, sl_h, *PATTERN, bm, bn, ops.MODES["triangle"], ops.units_per_item(H, Hkv),
+                                    num_cus=256)
+    sz = ops.index_sizes(cu_h, sl_h, *PATTERN, bm, bn, ops.MODES["triangle"], chunk_tiles=chunk)
+    t = torch.tensor([float(sz.num_items * ops.units_per_item(H, Hkv)), float(H), float(Hkv)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": metric_name(cfg, n), "value": None, "unit": "tokens/s", "n_gpus": world, "steps": 0,
+                          "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": workload_name(cfg, n), "global_batch": batch, "seq_len": n,
+                                     "heads_per_gpu": int(t[1]), "kv_heads_per_gpu": int(t[2]),
+                                     "head_dim": cfg["head_dim"], "parallelism": f"tp{world} (heads)",
+                                     "work_units_per_gpu": int(t[0]), "chunk_tiles": chunk}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def metric_name(cfg, n):
+    return (f"prefill tokens/sec (TriangleMix attention op, index build included), {cfg['name']} "
+            f"{n // 1024 if n % 1024 == 0 else n}{'k' if n % 1024 == 0 else '-token'} ctx")
+
+
+def workload_name(cfg, n):
+    return (f"{cfg['name']} {'fp8 K/V cache, bf16 arithmetic' if cfg['kv'] == 'fp8' else 'bf16'} seq_len={n} TriangleMix "
+            f"prefill (one attention layer: block-index build + masked attention), sink/window/last={PATTERN}, "
+            f"paged KV page {PAGE}")
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    cfg = MODELS[args.model]
+    n = args.seq_len or cfg["seq_len"]
+    if args.dry_run:
+        return dry_run(args, cfg, n, world, rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the TriangleMix path has no CPU fallback)")
     dev = torch.device("cuda", local_rank)
@@ -146,19 +269,19 @@ def main():
     from vllm_trianglemix_amd._lib import TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES, TMX_ATTN_SKIP_COMBINE
     from vllm_trianglemix_amd.parallel import RowParallelOutputProjection, shard_heads
 
-    n = args.seq_len
+    fp8 = cfg["kv"] == "fp8"
     job_world = args.emulate_world if (args.emulate_world > 0 and world == 1) else world
-    shard = shard_heads(QWEN3_8B["num_heads"], QWEN3_8B["num_kv_heads"], rank, job_world)
-    H, Hkv, D = shard.num_heads, shard.num_kv_heads, QWEN3_8B["head_dim"]
+    shard = shard_heads(cfg["num_heads"], cfg["num_kv_heads"], rank, job_world)
+    H, Hkv, D = shard.num_heads, shard.num_kv_heads, cfg["head_dim"]
     batch = job_world  # weak scaling: one more prompt per GPU
-    inp = make_inputs(ops, dev, n, batch, H, Hkv, D, seed=0)  # same prompts on every rank, different head shards
+    inp = make_inputs(ops, dev, n, batch, H, Hkv, D, seed=0, fp8=fp8)  # same prompts on every rank, different head shards
     si, sl, last = PATTERN
     bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
     scale = D ** -0.5
     out = torch.empty_like(inp["q"])
     kc, vc = inp["kv_cache"][0], inp["kv_cache"][1]
 
-    def build(mode):
+    def build(mode, pages=True):
         # pages of every listed tile are resolved by the builder (block table lookups leave the attention loop);
         # the piece length is the library's advice for this batch (one piece of the dense rows per CU: 64 tiles here)
         if mode == "triangle" and args.chunk_tiles > 0:
@@ -166,17 +289,35 @@ def main():
         else:
             chunk = ops.suggest_chunk_tiles(inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn, ops.MODES[mode],
                                             ops.units_per_item(H, Hkv))
+        if not pages:
+            return ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn,
+                                         ops.MODES[mode], chunk_tiles=chunk)
         return ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn,
                                      ops.MODES[mode], chunk_tiles=chunk, block_table=inp["block_table"],
                                      page_size=PAGE)
 
-    idx0 = build("triangle")
+    idx0 = build("triangle", pages=not fp8)
     work = ops.alloc_workspace(idx0, H, D, dev)
 
+    if fp8:
+        # fp8 K/V cache: the step's keys and values leave the cache through the descale pass (fp8 x scale ->
+        # bf16 rows kept for the step), then the attention runs on those rows
+        rows = (torch.empty((batch * n, Hkv, D), dtype=torch.bfloat16, device=dev),
+                torch.empty((batch * n, Hkv, D), dtype=torch.bfloat16, device=dev))
+
+        def attend(idx, flags=0):
+            if not (flags & TMX_ATTN_ONLY_COMBINE):
+                ops.gather_dequant_kv_fp8(kc, vc, inp["block_table"], inp["sl"], inp["cu"], batch * n, n,
+                                          torch.bfloat16, 1.0, 1.0, out=rows)
+            ops.attention(inp["q"], rows[0], rows[1], out, idx, inp["cu"], inp["sl"], scale, cu_seqlens_k=inp["cu"],
+                          workspace=work, flags=flags)
+    else:
+        def attend(idx, flags=0):
+            ops.attention(inp["q"], kc, vc, out, idx, inp["cu"], inp["sl"], scale, block_table=inp["block_table"],
+                          workspace=work, flags=flags)
+
     def step():
-        idx = build("triangle")
-        ops.attention(inp["q"], kc, vc, out, idx, inp["cu"], inp["sl"], scale, block_table=inp["block_table"],
-                      workspace=work)
+        attend(build("triangle", pages=not fp8))
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -220,21 +361,20 @@ def main():
         return float(np.mean([a.elapsed_time(b) for a, b in evs]))  # ms
 
     def attn_only():
-        ops.attention(inp["q"], kc, vc, out, idx0, inp["cu"], inp["sl"], scale, block_table=inp["block_table"],
-                      workspace=work, flags=TMX_ATTN_SKIP_COMBINE)
+        attend(idx0, TMX_ATTN_SKIP_COMBINE)
 
     def combine_only():
-        ops.attention(inp["q"], kc, vc, out, idx0, inp["cu"], inp["sl"], scale, block_table=inp["block_table"],
-                      workspace=work, flags=TMX_ATTN_ONLY_COMBINE)
+        attend(idx0, TMX_ATTN_ONLY_COMBINE)
 
     iters = max(5, min(args.steps, 50))
     for _ in range(3):
         attn_only()
     t_attn_ms = timed(attn_only, iters)
     t_comb_ms = timed(combine_only, iters)
-    t_index_ms = timed(lambda: build("triangle"), iters)
-    # algorithmic bytes per token per attention call: Q read + O write + K read + V read, 16-bit elements
-    bytes_per_token = 2 * (H + Hkv) * D * 2
+    t_index_ms = timed(lambda: build("triangle", pages=not fp8), iters)
+    # algorithmic bytes per token per attention call: Q read + O write (16-bit) + K read + V read (16-bit, or one
+    # byte each out of an fp8 cache)
+    bytes_per_token = 2 * H * D * 2 + 2 * Hkv * D * (1 if fp8 else 2)
     algo_bytes = bytes_per_token * batch * n
     achieved = algo_bytes / (t_attn_ms * 1e-3) / 1e9
     # HBM-side bytes per launch of the same kernel on the same workload, from two rocprofv3 --pmc
@@ -253,7 +393,7 @@ def main():
                 "kernel_ms": t_attn_ms, "combine_ms": t_comb_ms, "index_build_ms": t_index_ms}
 
     extra = {}
-    if not args.no_baselines and rank == 0:
+    if not args.no_baselines and rank == 0 and not fp8:
         # dense-causal baselines at the same shape (attention-op level)
         try:
             idx_c = build("causal")
@@ -275,6 +415,13 @@ def main():
                              "triangle_TFLOPs": fl_tri / (t_attn_ms * 1e-3) / 1e12,
                              "triangle_frac_of_peak": fl_tri / (t_attn_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS}
             extra["speedup_vs_own_dense"] = t_dense / (ms_per_step)
+            # attention of the whole model with the reference's preset for this size (trianglemix_config.py:65-72:
+            # 8 triangle layers for an 8B model, 12 for 32B; the other layers attend causally above 2048 tokens)
+            layers, tri_layers = {"8b": (36, 8), "32b": (64, 12)}.get(args.model, (80, 8))
+            t_model = tri_layers * ms_per_step + (layers - tri_layers) * t_dense
+            extra["whole_model_attention"] = {"layers": layers, "triangle_layers": tri_layers, "ms": t_model,
+                                              "tokens_per_s": batch * n / (t_model * 1e-3),
+                                              "all_dense_ms": layers * t_dense}
             del work_c
         except Exception as e:  # pragma: no cover
             extra["dense_causal_own_kernel_error"] = repr(e)
@@ -294,7 +441,7 @@ def main():
         except Exception as e:  # pragma: no cover
             extra["dense_causal_torch_sdpa_error"] = repr(e)[:200]
 
-    if not args.no_baselines and rank == 0 and world == 1:
+    if not args.no_baselines and rank == 0 and world == 1 and not fp8:
         # decode step of the same model (every decode row is a dense last row of the pattern): 64 requests with
         # 8192 cached tokens each, one query row per request; the kernel streams the K/V of every request once
         try:
@@ -330,7 +477,7 @@ def main():
             extra["decode_error"] = repr(e)[:200]
 
     if args.oproj:
-        hidden = QWEN3_8B["hidden"]
+        hidden = cfg["hidden"]
         w = (torch.randn((hidden, H * D), device=dev) * 0.02).bfloat16()
         proj = RowParallelOutputProjection(w, chunk_tokens=8192 if world > 1 else 0)
         proj(out)
@@ -343,16 +490,15 @@ def main():
 
     cpu = None
     if not args.no_baselines and rank == 0 and world == 1:
-        cpu = cpu_baseline(n, QWEN3_8B["num_heads"], D, args.cpu_rows, args.cpu_heads)
+        cpu = cpu_baseline(n, cfg["num_heads"], D, args.cpu_rows, args.cpu_heads)
 
     if rank == 0:
         line = {
-            "metric": "prefill tokens/sec (TriangleMix attention op, index build included), Qwen3-8B 32k ctx",
+            "metric": metric_name(cfg, n),
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "settle_ms": args.settle_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Qwen3-8B bf16 seq_len={n} TriangleMix prefill (one attention layer: block-index "
-                                   f"build + masked attention), sink/window/last={PATTERN}, paged KV page {PAGE}",
+            "config": {"workload": workload_name(cfg, n),
                        "global_batch": batch, "seq_len": n, "heads_per_gpu": H, "kv_heads_per_gpu": Hkv,
                        "head_dim": D, "parallelism": f"tp{world} (heads)" if world > 1 else
                        (f"rank 0 of an emulated tp{job_world} job" if job_world > 1 else "single GPU")},

@@ -38,7 +38,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _worker(rank: int, world: int, port: int, kv_heads_total: int, out_path: str):
+def _worker(rank: int, world: int, port: int, kv_heads_total: int, out_path: str, chunk_tokens: int = 0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -47,7 +47,7 @@ def _worker(rank: int, world: int, port: int, kv_heads_total: int, out_path: str
         sh = shard_heads(H, kv_heads_total, rank, world)
         local = _attend(q[:, sh.head_slice], k[:, sh.kv_head_slice], v[:, sh.kv_head_slice])
         w_shard = torch.from_numpy(np.ascontiguousarray(w[:, sh.head_start * D:(sh.head_start + sh.num_heads) * D]))
-        proj = RowParallelOutputProjection(w_shard)
+        proj = RowParallelOutputProjection(w_shard, chunk_tokens=chunk_tokens)
         y = proj(torch.from_numpy(local.astype(np.float32)))
         if rank == 0:
             np.save(out_path, y.numpy())
@@ -65,3 +65,13 @@ def test_two_ranks_equal_one(tmp_path, kv_heads_total):
     full = _attend(q, k, v).astype(np.float32).reshape(N, H * D) @ w.T
     got = np.load(out_path)
     np.testing.assert_allclose(got, full, rtol=1e-5, atol=1e-5)
+
+
+def test_chunked_output_projection_equals_one_all_reduce(tmp_path):
+    """chunk_tokens > 0: the token dimension goes through GEMM + all-reduce in pieces (96 tokens in chunks of
+    40: two full chunks and a ragged one); the sum must equal the single all-reduce."""
+    out_path = str(tmp_path / "y.npy")
+    mp.spawn(_worker, args=(2, _free_port(), 4, out_path, 40), nprocs=2, join=True)
+    q, k, v, w = _inputs()
+    full = _attend(q, k, v).astype(np.float32).reshape(N, H * D) @ w.T
+    np.testing.assert_allclose(np.load(out_path), full, rtol=1e-5, atol=1e-5)

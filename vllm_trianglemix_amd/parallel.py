@@ -81,19 +81,30 @@ class RowParallelOutputProjection(torch.nn.Module):
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world == 1:
             return x @ self.weight_shard.t()
-        if self.chunk_tokens <= 0 or t <= self.chunk_tokens or not x.is_cuda:
+        if self.chunk_tokens <= 0 or t <= self.chunk_tokens:
             y = x @ self.weight_shard.t()
             dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
             return y
+        # chunks of the token dimension: the all-reduce of chunk c runs beside the GEMM of chunk c + 1 (on a
+        # second HIP stream for device tensors, as asynchronous collectives for host tensors)
         y = torch.empty((t, self.weight_shard.shape[0]), dtype=x.dtype, device=x.device)
-        if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=x.device)
-        main = torch.cuda.current_stream(x.device)
+        pending = []
+        main = None
+        if x.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=x.device)
+            main = torch.cuda.current_stream(x.device)
         for lo in range(0, t, self.chunk_tokens):
             hi = min(t, lo + self.chunk_tokens)
             torch.matmul(x[lo:hi], self.weight_shard.t(), out=y[lo:hi])
-            self._comm_stream.wait_stream(main)
-            with torch.cuda.stream(self._comm_stream):
-                dist.all_reduce(y[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
-        main.wait_stream(self._comm_stream)
+            if main is not None:
+                self._comm_stream.wait_stream(main)
+                with torch.cuda.stream(self._comm_stream):
+                    dist.all_reduce(y[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                pending.append(dist.all_reduce(y[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for work in pending:
+            work.wait()
+        if main is not None:
+            main.wait_stream(self._comm_stream)
         return y
