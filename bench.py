@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--chunk-tiles", type=int, default=0,
                     help="piece length of the dense rows in key tiles (0: the library's advice for the batch)")
     ap.add_argument("--cpu-heads", type=int, default=8, help="heads of the CPU-baseline sample")
+    ap.add_argument("--no-band", action="store_true",
+                    help="A/B aid: every q-block through the work list (no band workgroups for the sparse q-blocks)")
     return ap.parse_args()
 
 
@@ -266,7 +268,9 @@ def main():
     torch.cuda.set_device(dev)
 
     from vllm_trianglemix_amd import ops
-    from vllm_trianglemix_amd._lib import TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES, TMX_ATTN_SKIP_COMBINE
+    from vllm_trianglemix_amd._lib import (TMX_ATTN_NO_BAND, TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES,
+                                           TMX_ATTN_SKIP_COMBINE)
+    base_flags = TMX_ATTN_NO_BAND if args.no_band else 0
     from vllm_trianglemix_amd.parallel import RowParallelOutputProjection, shard_heads
 
     fp8 = cfg["kv"] == "fp8"
@@ -306,6 +310,7 @@ def main():
                 torch.empty((batch * n, Hkv, D), dtype=torch.bfloat16, device=dev))
 
         def attend(idx, flags=0):
+            flags |= base_flags
             if not (flags & TMX_ATTN_ONLY_COMBINE):
                 ops.gather_dequant_kv_fp8(kc, vc, inp["block_table"], inp["sl"], inp["cu"], batch * n, n,
                                           torch.bfloat16, 1.0, 1.0, out=rows)
@@ -314,7 +319,7 @@ def main():
     else:
         def attend(idx, flags=0):
             ops.attention(inp["q"], kc, vc, out, idx, inp["cu"], inp["sl"], scale, block_table=inp["block_table"],
-                          workspace=work, flags=flags)
+                          workspace=work, flags=flags | base_flags)
 
     def step():
         attend(build("triangle", pages=not fp8))

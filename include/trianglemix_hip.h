@@ -258,6 +258,9 @@ typedef struct tmx_attention_args_t {
 #define TMX_ATTN_SKIP_COMBINE 1u
 #define TMX_ATTN_ONLY_COMBINE 2u
 #define TMX_ATTN_SHORT_QUERIES 4u
+/* Measurement aid: every q-block goes through the work list (the band workgroups that otherwise take the
+ * sparse q-blocks in canonical position are not launched).  Results do not depend on it. */
+#define TMX_ATTN_NO_BAND 8u
 
 int tmx_attention(const tmx_attention_args_t* args, void* stream);
 

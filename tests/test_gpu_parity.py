@@ -1106,3 +1106,42 @@ def test_backend_length_gate_2048_vs_2049(golden_attention):
     # the reference's own fp32 run on the same (bf16-representable) inputs
     want = arrays["helper_tri_2049"][0]
     assert float(np.abs(got[2048:] - want).max()) <= ATOL_F32_OUT
+
+
+@pytest.mark.parametrize("case", [
+    # (q_lens, seq_lens, H, Hkv, D, pattern, dtype, paged, page, full_lens)
+    dict(q=[3000], s=[3000], H=8, Hkv=2, D=128, pat=(4, 32, 64)),                                   # one prompt
+    dict(q=[1024, 700, 1], s=[3072, 700, 900], H=8, Hkv=2, D=128, pat=(4, 32, 64), paged=True),     # context a multiple of 32
+    dict(q=[1000, 2500], s=[3047, 2500], H=8, Hkv=2, D=128, pat=(4, 32, 64), paged=True),           # ... and not (no band)
+    dict(q=[2600], s=[2600], H=16, Hkv=2, D=64, pat=(0, 17, 1), dtype=torch.float16),               # 8 heads per K/V head
+    dict(q=[2400, 2400], s=[2400, 2400], H=4, Hkv=1, D=128, pat=(15, 31, 200), paged=True, page=64),
+    dict(q=[2200], s=[2200], H=4, Hkv=1, D=64, pat=(-1, 32, 0), out=torch.bfloat16),                # no sink, no dense rows
+    dict(q=[512, 512], s=[2560, 3072], H=8, Hkv=2, D=128, pat=(4, 32, 64), paged=True, full=[6000, 3072]),  # chunks
+])
+def test_band_path_matches_oracle_and_work_list(case):
+    """Sparse q-blocks in canonical position (32 full rows at a multiple of 32, clear of the sink tile and of
+    the trailing dense rows) run on the band workgroups.  Same results as the oracle, and as the same launch
+    with every q-block on the work list (TMX_ATTN_NO_BAND), for patterns at the edges of what the band path
+    takes (window 17..32, sink -1..15), grouped heads 4 and 8, both head sizes, paged and contiguous K/V,
+    requests with context, chunked prompts."""
+    from vllm_trianglemix_amd._lib import TMX_ATTN_NO_BAND
+    ops = _ops()
+    q_lens, seq_lens, H, Hkv, D = case["q"], case["s"], case["H"], case["Hkv"], case["D"]
+    si, sl, last = case["pat"]
+    dtype, out_dtype = case.get("dtype", torch.bfloat16), case.get("out", torch.float32)
+    q, ks, vs = _rand_case(909 + H + D, q_lens, seq_lens, H, Hkv, D)
+    if dtype == torch.float16:
+        q, ks, vs = (np.float16(q).astype(np.float32), [np.float16(k).astype(np.float32) for k in ks],
+                     [np.float16(v).astype(np.float32) for v in vs])
+    scale = D ** -0.5
+    kw = dict(dtype=dtype, out_dtype=out_dtype, paged=case.get("paged", False), page_size=case.get("page", 16),
+              full_lens=case.get("full"), gate=2048)
+    got = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, "triangle", (si, sl, last), **kw)
+    plain = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, "triangle", (si, sl, last), flags=TMX_ATTN_NO_BAND, **kw)
+    cu = np.concatenate([[0], np.cumsum(q_lens)])
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu, seq_lens, scale, "triangle", si, sl, last,
+                                   full_lens=case.get("full"), tri_min_len=2048)
+    tol = ATOL_F32_OUT + (np.abs(ref) * 2.0 ** -8 if out_dtype != torch.float32 else 0.0)
+    assert not np.isnan(got).any()
+    assert np.all(np.abs(got - ref) <= tol), np.abs(got - ref).max()
+    assert np.all(np.abs(plain - ref) <= tol), np.abs(plain - ref).max()

@@ -22,13 +22,21 @@ idx = ops.build_block_index(cu, sl, cu_h, sl_h, pat[0], pat[1], pat[2], ops.atte
                             ops.MODES[pat[3]], chunk_tiles=chunk)
 need = max(1, int(idx.sizes.num_partials) * H * idx.block_m)
 po = torch.empty((need * D,), dtype=torch.float32, device=dev)
-pml = torch.zeros((max(need * 2, 1 << 20),), dtype=torch.float32, device=dev)
+assert need * 2 <= 1 << 19
+pml = torch.zeros((1 << 21,), dtype=torch.float32, device=dev)  # (max, sum) pairs, then from float 2^19 on the stamps
 for _ in range(3):
     ops.attention(q, k, v, out, idx, cu, sl, D ** -0.5, cu_seqlens_k=cu, workspace=(po, pml), flags=TMX_ATTN_SKIP_COMBINE)
 torch.cuda.synchronize()
-st = pml.view(torch.int64)[: 512 * 8 * 8].view(-1, 8, 8).cpu().numpy()  # [workgroup, wave, segment]
-st = st[st[:, 0, 6] > 0]
-names = ["wait", "barrier", "issue", "tile compute", "epilogue", "next unit", "TOTAL", "steps"]
+role = sys.argv[4] if len(sys.argv) > 4 else "list"   # "list": work-list workgroups, "band": band workgroups
+allst = pml[1 << 19:].view(torch.int64)[: 4096 * 8 * 8].view(-1, 8, 8).cpu().numpy()  # [workgroup, wave, segment]
+n_list = min(512, 4 * max(int(idx.sizes.num_partials), 4) * 8 // 4)  # work-list workgroups come first in the grid
+if role == "band":
+    st = allst[256:]
+    names = ["wait vmcnt", "barrier", "scores", "issue", "softmax", "PV + store", "TOTAL", "steps"]
+else:
+    st = allst[:256]
+    names = ["wait", "barrier", "issue", "tile compute", "epilogue", "next unit", "TOTAL", "steps"]
+st = st[(st[:, 0, 6] > 0) & (st[:, 0, 7] > 0)]
 tot = st[:, :, 6].mean()
 print(f"{mode} n={n}: {len(st)} workgroups, mean total {tot:.0f} cycles (100 MHz ticks? see below), steps/wave {st[:, :, 7].mean():.1f}")
 for i, nm in enumerate(names[:6]):

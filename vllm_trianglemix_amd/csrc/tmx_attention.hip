@@ -137,6 +137,11 @@ struct AttnParams {
   int num_items;
   int issue_hi;               // waves 4..7 fetch the K/V entries (TMX_ATTN_SHORT_QUERIES)
   int num_heavy, sched_w;     // the first num_heavy items are pieces of split q-blocks; light items per piece (schedule)
+  int band_on;                // sparse q-blocks in canonical position run on the band path (their own workgroups)
+  int band_rl;                // q-blocks per band workgroup
+  int n_generic;              // workgroups 0 .. n_generic - 1 walk the work list, the others are band workgroups
+  int num_qblocks;            // q-blocks of the batch
+  int exp_mode;               // tuning builds: 1 = work-list workgroups return at once, 2 = band workgroups do
   long long units_total;      // work items x Y
   int mode, si, sl, last, tri_min_len;
   int bias_rows, bias_cols, bias_dtype, out_dtype;
@@ -179,6 +184,12 @@ __device__ __forceinline__ int opaque(int x) {
   asm volatile("" : "+v"(x));
   return x;
 }
+// This lane's number inside its wave, computed on the spot (two v_mbcnt): rare paths inside the main loops
+// use it instead of a value derived from threadIdx at kernel entry, which would stay live (or be spilled and
+// reloaded, with a wait for every transfer in flight) across the whole loop.
+__device__ __forceinline__ int lane_now() {
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
 
 template <typename F>
 __device__ __forceinline__ F lds_read_b128(unsigned addr) {
@@ -193,21 +204,6 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-// Diagnostic builds only (-DTMX_STAMPS): per-wave cycle sums of the loop's segments, written to a
-// buffer of their own.  No stamp executes in the shipped library.
-#ifdef TMX_STAMPS
-#define TMX_STAMP(var)                                                                   \
-  do {                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-  } while (0)
-#define TMX_SEG(idx, t0, t1) seg[idx] += (t1) - (t0)
-#else
-#define TMX_STAMP(var) do { } while (0)
-#define TMX_SEG(idx, t0, t1) do { } while (0)
-#endif
-
 // Running maximum before any key was seen: finite, so that exp2(m_old - m_new) and exp2(-inf - m)
 // need no special cases (scores are finite; a fully masked row still ends with sum 0 -> NaN).
 constexpr float kMinusBig = -1.0e30f;
@@ -215,6 +211,7 @@ constexpr float kMinusBig = -1.0e30f;
 // Workgroup shape of the attention kernel: 4 (head, 32-row) slots x 2 sixteen-row blocks = 8 waves
 // of 16 query rows each; all of them share the K/V tiles of one K/V head.
 constexpr int kWaves = 2 * kWavesPerWG;
+constexpr int kRingSlots = 3;  // K/V ring entries of the attention kernel (plus a private Q region per wave)
 // Key tiles per softmax step.
 constexpr int kGroupMax = 1;
 // The running row maximum is kept until a tile's maximum exceeds it by more than this (log2 units).
@@ -261,6 +258,341 @@ __device__ __forceinline__ void wait_vmcnt_levels(int n) {
   else wait_vmcnt<0>();
 }
 
+// Diagnostic builds only (-DTMX_STAMPS): per-wave cycle sums of the loop's segments, written to a
+// buffer of their own.  No stamp executes in the shipped library.
+#ifdef TMX_STAMPS
+#define TMX_STAMP(var)                                                                   \
+  do {                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+  } while (0)
+#define TMX_SEG(idx, t0, t1) seg[idx] += (t1) - (t0)
+#else
+#define TMX_STAMP(var) do { } while (0)
+#define TMX_SEG(idx, t0, t1) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// Band path.  In a long triangle request almost every q-block is in "canonical position": 32 full rows
+// starting at a multiple of 32, none of them among the trailing dense rows, its window clear of the sink
+// columns' tile.  Such a q-block attends to the 16-key group of the sink columns and to the 64 keys
+// [pos0 - 32, pos0 + 32); each of its two 16-row halves to the sink group and 48 of those keys.  That is a
+// fixed shape: ONE softmax step over four 16-key groups per wave, masks that depend on the lane only, and
+// consecutive q-blocks share three quarters of their keys.  A band workgroup takes a run of consecutive
+// q-blocks of one K/V head chunk and keeps a rolling window of 16-key halves ([K | V], LDS-DMA) in LDS:
+// per q-block it fetches 32 new keys, the query rows go straight to registers (fetched one q-block ahead,
+// once the score products no longer need the previous ones), one barrier per q-block.
+//
+// Whether a q-block takes this path is decided by the same function in the band workgroups (which walk
+// q-blocks) and in the workgroups that walk the work list (which skip such items).
+struct BandRule {
+  int sl, last, mode, tri_min_len;
+};
+
+// q-block at position pos0 of a request with n keys so far, n_full once its prompt is complete
+__device__ __forceinline__ bool band_qblock(const BandRule& r, int pos0, int n, int n_full) {
+  return (pos0 & 31) == 0 && pos0 >= 64 && n - pos0 >= 32 && (n_full - (pos0 + 31)) >= r.last &&
+         effective_mode(r.mode, n_full, r.tri_min_len) == TMX_MODE_TRIANGLE;
+}
+
+template <typename TR, int D, bool PAGED>
+__device__ __forceinline__ void band_body(const AttnParams& p, const unsigned lds_base, const int band_id) {
+  constexpr int KS = D / 32, DB = D / 16, ROWB = D * 2, CPR = D / 8;
+  constexpr int RPP = 1024 / ROWB;   // rows per 1-KiB LDS-DMA piece
+  constexpr int HALFB = 32 * ROWB;   // a 16-key half: [K 16 rows | V 16 rows]
+  constexpr int NSLOT = 8;           // rolling window: 4 halves in use, 4 arriving (two q-blocks ahead)
+  constexpr int PWB = 8 / RPP;       // pieces per wave and pair of halves (8 rows of one tensor)
+  constexpr bool PRECISE = TR::kSplitP;
+  using frag = typename TR::frag;
+  static_assert((NSLOT + 1) * HALFB <= kRingSlots * 64 * ROWB + kWaves * 16 * ROWB, "band window does not fit the kernel's LDS");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 15, g = lane >> 4;
+  const int hg = wave & 3, hf = wave >> 2;  // head of the group, 16-row half of the q-block
+  const int kvc = band_id % p.Y;
+  const int run = band_id / p.Y;
+  const int chunks = p.G / p.Gw;
+  const int kvh = kvc / chunks;
+  const int head = kvh * p.G + (kvc - kvh * chunks) * p.Gw + hg;
+  const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = 2 * p.kv_stride_t;
+
+  // ---- LDS-DMA share of this wave: 8 rows of K or of V of one half of each pair ----
+  const int t_v = (wave & 3) >> 1;        // 0: K rows, 1: V rows
+  const int r8 = 8 * (wave & 1);          // rows r8 .. r8 + 7 of the half
+  const char* const kv_src = reinterpret_cast<const char*>(t_v ? p.v : p.k) + 2ll * kvh * p.kv_stride_h;
+  int kv_voff[PWB];
+#pragma unroll
+  for (int x = 0; x < PWB; ++x) {
+    const int row = r8 + x * RPP + lane / CPR;
+    kv_voff[x] = row * kv_row_bytes + 16 * ((lane % CPR) ^ (t_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row)));
+  }
+  const unsigned dma_off = (unsigned)(t_v * 16 * ROWB + r8 * ROWB);
+  const unsigned sink_base = lds_base + NSLOT * HALFB;
+  auto slot_base = [&](int half_no) { return lds_base + (unsigned)(half_no % NSLOT) * HALFB; };
+
+  // ---- compute side: per-lane read offsets inside a half, lane-constant masks ----
+  const int k_base = qi * ROWB + 16 * (g ^ k_chunk_swizzle<D>(qi));
+  const int v_row = 4 * g + ((lane & 15) >> 2);
+  const int v_base = 16 * ROWB + v_row * ROWB + 8 * (lane & 3) + 32 * (v_chunk_swizzle<D>(v_row) >> 1);
+  // this lane's row is row qi of the wave's 16, its 4 keys of a 16-key group are 4 g .. 4 g + 3.  Group A
+  // starts 32 keys below the wave's first row, B 16 below, C at it: distance row - key = qi + {32, 16, 0} - key.
+  // sink group: key <= si; A: row - key = qi + 32 - key <= sl; B: qi + 16 - key <= sl; C: key <= qi.  In terms
+  // of the lane's element c (key = 4 g + c): c <= c_sink, c >= c_win (A), c >= c_win - 16 (B), c <= c_diag.
+  const int c_sink = p.si - 4 * g, c_win = qi + 32 - p.sl - 4 * g, c_diag = qi - 4 * g;
+  const float mult = p.scale_log2;
+  // query rows and output rows: wave-uniform base of the wave's 16 rows + this lane's 32-bit offset
+  const char* const q_head = reinterpret_cast<const char*>(p.q) + 2ll * head * p.q_stride_h;
+  const int q_lane = qi * q_row_bytes + 16 * g;
+  auto load_q = [&](int q_tok0, frag (&q)[KS]) {
+    const char* rows = q_head + (long long)(q_tok0 + 16 * hf) * q_row_bytes;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      q[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(rows + (q_lane + 64 * ks)));
+  };
+
+  int qb = run * p.band_rl;
+  const int qb_end = imin(p.num_qblocks, qb + p.band_rl);
+  bool fresh = true;  // nothing of this workgroup is in flight or being read
+#ifdef TMX_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, ts6;
+  TMX_STAMP(ts0);
+  const unsigned long long t_begin = ts0;
+#endif
+#pragma unroll 1
+  while (qb < qb_end) {
+    // ---- next segment: consecutive band q-blocks of one request inside [qb, qb_end) ----
+    const int b = sload(p.qb_meta + 2 * qb), row0 = sload(p.qb_meta + 2 * qb + 1);
+    const int q_start = sload(p.cu_q + b);
+    const int q_len = sload(p.cu_q + b + 1) - q_start;
+    const int n = sload(p.seq_lens + b);
+    const int nf = p.full_lens != nullptr ? imax(n, sload(p.full_lens + b)) : n;
+    const int ctx = n - q_len;
+    const int blocks_left = (q_len - row0 + 31) / 32;  // q-blocks of this request from qb on
+    // band q-blocks of the request are k_lo .. k_hi - 1 (k = row0 / 32)
+    int k_lo = 0, k_hi = 0;
+    if ((ctx & 31) == 0 && effective_mode(p.mode, nf, p.tri_min_len) == TMX_MODE_TRIANGLE) {
+      k_lo = ctx >= 64 ? 0 : (64 - ctx) / 32;
+      const int lim = nf - p.last - 31 - ctx;
+      k_hi = lim >= 0 ? imin(q_len / 32, lim / 32 + 1) : 0;
+    }
+    const int k0 = row0 / 32;
+    const int k_first = imax(k0, k_lo);
+    const int k_stop = imin(k_hi, k0 + imin(blocks_left, qb_end - qb));
+    const int qb_next = qb + imin(blocks_left, qb_end - qb);  // where the walk goes on after this request
+    if (k_first >= k_stop) {
+      qb = qb_next;
+      continue;
+    }
+    const long long krow0 = PAGED ? 0 : (long long)sload(p.cu_k + b);
+    const int32_t* const bt = PAGED ? p.block_table + (long long)b * p.block_table_stride : nullptr;
+    // byte offset of the 16-key half that starts at key0 (one page, or part of one, of a paged cache)
+    auto half_offset = [&](int key0) -> long long {
+      if constexpr (PAGED)
+        return 2ll * sload(bt + (key0 >> p.page_shift)) * p.kv_stride_page + (long long)(key0 & (p.page_size - 1)) * kv_row_bytes;
+      else return (krow0 + key0) * kv_row_bytes;
+    };
+    auto issue_at = [&](long long off, unsigned half_base) {
+#pragma unroll
+      for (int x = 0; x < PWB; ++x) glds16_s(kv_src + off, kv_voff[x], half_base + dma_off + x * 1024);
+    };
+    // pair of halves: waves 0..3 fetch the first, waves 4..7 the second (a key below 0: nothing)
+    auto issue_pair = [&](int key_a, unsigned base_a, int key_b, unsigned base_b) {
+      const int key = hf ? key_b : key_a;
+      if (key >= 0) issue_at(half_offset(key), hf ? base_b : base_a);
+    };
+
+    if (!fresh) {
+      // every wave is done with the halves of the previous segment before they are overwritten
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    fresh = false;
+    int k = k_first;
+    int pos0 = ctx + 32 * k;
+    int h0 = pos0 / 16 - 2;  // the q-block's halves are h0 .. h0 + 3 (16-key groups of the request)
+    // Run-ahead: while q-block k is computed, the keys of k + 1 and k + 2 and the query rows of k + 1 are on
+    // their way (one band workgroup beside an arithmetic-bound piece on the same CU has to keep the CU's
+    // share of the memory system busy by itself).  qa holds the query rows of k, k + 2, ..., qb_ those of
+    // k + 1, k + 3, ...: the rows of the next q-block are asked for at the top of a q-block, into the set
+    // that q-block does not use.
+    frag qa[KS], qb_[KS];
+    issue_pair(0, sink_base, 16 * h0, slot_base(h0));
+    issue_pair(16 * (h0 + 1), slot_base(h0 + 1), 16 * (h0 + 2), slot_base(h0 + 2));
+    issue_pair(16 * (h0 + 3), slot_base(h0 + 3), -1, 0);
+    load_q(q_start + 32 * k, qa);
+    if (k + 1 < k_stop) issue_pair(16 * (h0 + 4), slot_base(h0 + 4), 16 * (h0 + 5), slot_base(h0 + 5));
+    bool first = true;
+
+    // one q-block: its query rows are in `cur`, the next q-block's go to `nxt`
+    auto one_qblock = [&](const frag (&cur)[KS], frag (&nxt)[KS]) {
+      const bool has1 = k + 1 < k_stop, has2 = k + 2 < k_stop;
+      TMX_STAMP(ts0);
+      if (has1) load_q(q_start + 32 * (k + 1), nxt);
+      // where this wave's half of the q-block after the next one lives (a block-table lookup: asked for
+      // here, used after the score products)
+      const long long off2 = has2 ? half_offset(16 * (h0 + 6 + hf)) : 0;
+      // Wait for this q-block's halves and query rows: what the wave issued later may stay in flight -- the
+      // next q-block's pieces, the output rows stored last, the next q-block's query rows.
+      {
+        const int st = first ? 0 : (p.out_dtype == TMX_F32 ? DB : DB / 2);
+        const int n = (has1 ? PWB + KS : 0) + st;
+        if (n == PWB + KS + DB / 2) wait_vmcnt<PWB + KS + DB / 2>();
+        else if (n == PWB + KS + DB) wait_vmcnt<PWB + KS + DB>();
+        else if (n == PWB + KS) wait_vmcnt<PWB + KS>();
+        else if (n == DB / 2) wait_vmcnt<DB / 2>();
+        else if (n == DB) wait_vmcnt<DB>();
+        else wait_vmcnt<0>();
+      }
+      first = false;
+      TMX_STAMP(ts1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      TMX_STAMP(ts2);
+
+      // ---- scores of the four groups: sink, A, B, C ----
+      const unsigned gb[4] = {sink_base, slot_base(h0 + hf), slot_base(h0 + hf + 1), slot_base(h0 + hf + 2)};
+      f32x4 sc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto scores = [&](const frag (&qf)[KS]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const frag kf = lds_read_b128<frag>((gb[u] + k_base) ^ (64 * ks));
+            sc[u] = TR::mfma(kf, qf[ks], sc[u]);
+          }
+          // (the scheduler would otherwise fetch all sixteen K fragments ahead: 64 registers)
+          if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      scores(cur);
+      // the halves of the q-block before this one are free: fetch the keys of the q-block after the next one
+      asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3])::"memory");
+      TMX_STAMP(ts3);
+      if (has2) issue_at(off2, slot_base(h0 + 6 + hf));
+      TMX_STAMP(ts4);
+
+      // ---- one softmax step over the 16 scores of the lane's row ----
+      const float ninf = -__builtin_inff();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        sc[0][c] = c <= c_sink ? sc[0][c] : ninf;
+        sc[1][c] = c >= c_win ? sc[1][c] : ninf;
+        sc[2][c] = c >= c_win - 16 ? sc[2][c] : ninf;
+        sc[3][c] = c <= c_diag ? sc[3][c] : ninf;
+      }
+      float tmax = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
+                         fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+      tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(sc[2][0], sc[2][1]), fmaxf(sc[2][2], sc[2][3])),
+                               fmaxf(fmaxf(sc[3][0], sc[3][1]), fmaxf(sc[3][2], sc[3][3]))));
+      {
+        const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+        const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+      }
+      const float mneg = -tmax * mult;  // the row's own key is always attended: finite
+      uint32_t ph[8], pl[8];
+      float psum = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][c], mult, mneg));
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][c + 1], mult, mneg));
+          psum += p0 + p1;
+          TR::pack2(p0, p1, ph[2 * u + (c >> 1)], pl[2 * u + (c >> 1)]);
+        }
+
+      TMX_STAMP(ts5);
+      // ---- O^T = V^T P^T over two 32-key steps: (sink, A) and (B, C) ----
+      f32x4 acc[DB];
+#pragma unroll
+      for (int db = 0; db < DB; ++db) acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const frag pf = __builtin_bit_cast(frag, make_uint4(ph[4 * st], ph[4 * st + 1], ph[4 * st + 2], ph[4 * st + 3]));
+        const frag pq = __builtin_bit_cast(frag, make_uint4(pl[4 * st], pl[4 * st + 1], pl[4 * st + 2], pl[4 * st + 3]));
+        const unsigned va = gb[2 * st] + v_base, vb = gb[2 * st + 1] + v_base;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const s16x4 lo4 = lds_read_tr16_b64(va ^ (32 * db));
+          const s16x4 hi4 = lds_read_tr16_b64(vb ^ (32 * db));
+          const frag vf = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+          acc[db] = TR::mfma(vf, pf, acc[db]);
+          if constexpr (PRECISE) acc[db] = TR::mfma(vf, pq, acc[db]);
+          if ((db & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four V fragments fetched ahead
+        }
+      }
+
+      // ---- epilogue: lane (qi, g) holds columns 16 * db + 4 * g .. + 3 of its row ----
+      float l_tot;
+      {
+        const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(psum), __float_as_uint(psum), false, false);
+        l_tot = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+        const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+        l_tot = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+      }
+      const float inv = 1.0f / l_tot;
+      // (element offsets of the wave's 16 rows stay below 2^31: the strides are checked on the host)
+      const long long orows = (long long)(q_start + 32 * k + 16 * hf) * p.out_stride_t + (long long)head * p.out_stride_h;
+      if (p.out_dtype == TMX_F32) {
+        float* po = reinterpret_cast<float*>(p.out) + orows + (qi * p.out_stride_t + 4 * g);
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+          *reinterpret_cast<float4*>(po + 16 * db) =
+              make_float4(acc[db][0] * inv, acc[db][1] * inv, acc[db][2] * inv, acc[db][3] * inv);
+      } else {
+        uint16_t* po = reinterpret_cast<uint16_t*>(p.out) + orows + (qi * p.out_stride_t + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g));
+#pragma unroll
+        for (int c = 0; c < DB / 2; ++c) {
+          const f32x4 oa = acc[2 * c] * inv, ob = acc[2 * c + 1] * inv;
+          const uint2 au = make_uint2(TR::cvt2(oa[0], oa[1]), TR::cvt2(oa[2], oa[3]));
+          const uint2 bu = make_uint2(TR::cvt2(ob[0], ob[1]), TR::cvt2(ob[2], ob[3]));
+          const auto r0 = __builtin_amdgcn_permlane16_swap(au.x, bu.x, false, false);
+          const auto r1 = __builtin_amdgcn_permlane16_swap(au.y, bu.y, false, false);
+          *reinterpret_cast<uint4*>(po + 32 * c) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+      }
+      TMX_STAMP(ts6);
+      TMX_SEG(0, ts0, ts1);
+      TMX_SEG(1, ts1, ts2);
+      TMX_SEG(2, ts2, ts3);
+      TMX_SEG(3, ts3, ts4);
+      TMX_SEG(4, ts4, ts5);
+      TMX_SEG(5, ts5, ts6);
+#ifdef TMX_STAMPS
+      seg[7] += 1;
+#endif
+      ++k;
+      pos0 += 32;
+      h0 += 2;
+    };
+    // the two register sets swap roles from one q-block to the next
+#pragma unroll 1
+    for (;;) {
+      one_qblock(qa, qb_);
+      if (k >= k_stop) break;
+      one_qblock(qb_, qa);
+      if (k >= k_stop) break;
+    }
+    qb = qb_next;
+  }
+#ifdef TMX_STAMPS
+  TMX_STAMP(ts0);
+  seg[6] = ts0 - t_begin;
+  if (p.stamps != nullptr && lane == 0) {
+    unsigned long long* dst = p.stamps + ((size_t)blockIdx.x * kWaves + wave) * 8;
+    for (int x = 0; x < 8; ++x) dst[x] = seg[x];
+  }
+#endif
+}
+
 // Persistent, software-pipelined kernel.  Every workgroup walks work items
 // item0, item0 + step, ... for ONE K/V head chunk.  Their key tiles ([K | V],
 // 32 keys, one LDS entry each) stream through a ring of NS entries shared by
@@ -301,18 +633,34 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   const int qi = lane & 15, g = lane >> 4;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds));
+  // Two roles in one launch: workgroups 0 .. n_generic - 1 walk the work list (below), the others take runs
+  // of sparse q-blocks in canonical position (band_body).  One launch, so that the arithmetic-bound pieces of
+  // the dense rows and the memory-bound sparse q-blocks share the CUs.
+  const int bid = (int)blockIdx.x, ngrid = p.n_generic;
+  if constexpr (!HAS_BIAS) {
+    if (bid >= ngrid) {
+#ifdef TMX_TUNING
+      if (p.exp_mode == 2) return;
+#endif
+      band_body<TR, D, PAGED>(p, lds_base, bid - ngrid);
+      return;
+    }
+  }
+#ifdef TMX_TUNING
+  if (p.exp_mode == 1) return;
+#endif
 
   const int sub = wave & 3, half = wave >> 2;
   const int hg = sub & (p.Gw - 1);                  // this wave's head inside the workgroup's head group
   const int rb16 = (sub >> p.gw_shift) * 2 + half;   // its 16-row block inside the q-block
   // fixed for the workgroup: K/V head and query heads (the grid is a multiple of Y, or has <= Y workgroups)
-  const int kvc = blockIdx.x % p.Y;
+  const int kvc = bid % p.Y;
   const int chunks = p.G / p.Gw;
   const int kvh = kvc / chunks;
   const int head0 = kvh * p.G + (kvc - kvh * chunks) * p.Gw;
   const int head = head0 + hg;
-  const int item0 = blockIdx.x / p.Y;
-  const int item_step = (int)gridDim.x / p.Y;  // 0: every workgroup has a single item
+  const int item0 = bid / p.Y;
+  const int item_step = ngrid / p.Y;
 
   const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = 2 * p.kv_stride_t;
 
@@ -364,25 +712,33 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     sched_p1_base = P + item0 - r;
     sched_p2_base = P + e_total + item0 - sched_h * item_step;  // + k * item_step for the k-th item overall
   }
-  auto fetch_item = [&](int k, i32x4& a0, i32x4& a1) -> int {
-    // 32-bit on purpose: compared and indexed on the scalar unit
-    int item;
-    if (k < sched_h) item = item0 + k * item_step;
-    else if (k - sched_h < sched_e) item = sched_p1_base + (k - sched_h) * sched_short;
-    else item = sched_p2_base + (k - sched_e) * item_step;
-    const int ok = (item < p.num_items) && (k == 0 || item_step > 0);
-    a0 = a1 = i32x4{0, 0, 0, 1};
-    if (ok) {
+  // The schedule's next item that is this workgroup's to compute: with the band path on, items of
+  // q-blocks in canonical position belong to the band workgroups and are passed over here.
+  const BandRule band_rule{p.sl, p.last, p.mode, p.tri_min_len};
+  int sched_k = 0;
+  auto fetch_item = [&](i32x4& a0, i32x4& a1) -> int {
+#pragma unroll 1
+    for (;;) {
+      // 32-bit on purpose: compared and indexed on the scalar unit
+      const int k = sched_k++;
+      int item;
+      if (k < sched_h) item = item0 + k * item_step;
+      else if (k - sched_h < sched_e) item = sched_p1_base + (k - sched_h) * sched_short;
+      else item = sched_p2_base + (k - sched_e) * item_step;
+      const int ok = (item < p.num_items) && (k == 0 || item_step > 0);
+      a0 = a1 = i32x4{0, 0, 0, 1};
+      if (!ok) return 0;
       a0 = sload(reinterpret_cast<const i32x4*>(p.items) + 2ll * item);
       a1 = sload(reinterpret_cast<const i32x4*>(p.items) + 2ll * item + 1);
+      if (!p.band_on || a0.w >= 0) return 1;  // (pieces of split q-blocks never take the band path)
+      const int nf = p.full_lens != nullptr ? imax(a1.w, sload(p.full_lens + a1.x)) : a1.w;
+      if (!band_qblock(band_rule, a1.z, a1.w, nf)) return 1;
     }
-    return ok;
   };
   // the item being computed and the one after it
   i32x4 ca0, ca1, cb0, cb1;
-  int c_valid = fetch_item(0, ca0, ca1);
-  int cb_valid = fetch_item(1, cb0, cb1);
-  int ck = 0;
+  int c_valid = fetch_item(ca0, ca1);
+  int cb_valid = fetch_item(cb0, cb1);
 
   // ------------------------------------------------------------------ issue side (all scalar)
   // The issue cursor runs ahead of the compute side through the tile lists of the current item and of
@@ -926,8 +1282,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     ca0 = cb0;
     ca1 = cb1;
     c_valid = cb_valid;
-    ++ck;
-    cb_valid = fetch_item(ck + 1, cb0, cb1);
+    cb_valid = fetch_item(cb0, cb1);
     // the cursor follows: what was the next item is the current one now; a cursor that had nothing left
     // (the whole list of the new current item is issued) goes on into the new next item
     if (!issuer) {
@@ -1016,7 +1371,6 @@ __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p
   }
 }
 
-constexpr int kRingSlots = 3;  // K/V ring entries of the attention kernel (plus a private Q region per wave)
 
 // Persistent grid: as many workgroups as stay resident (LDS and registers allow a fixed number per
 // CU), rounded down to a multiple of the units per item so that a workgroup keeps one K/V head.
@@ -1024,11 +1378,12 @@ constexpr int kRingSlots = 3;  // K/V ring entries of the attention kernel (plus
 constexpr int kMaxDevices = 64;
 
 template <typename K>
-static int resident_workgroups(K kernel, unsigned* cache, long long* out) {
+static int resident_workgroups(K kernel, unsigned* cache, long long* out, int* cus_out) {
   int dev = 0;
   TMX_CHECK_HIP(hipGetDevice(&dev));
   if (dev >= 0 && dev < kMaxDevices && cache[dev] != 0) {
-    *out = cache[dev];
+    *out = cache[dev] & 0xFFFFF;
+    *cus_out = (int)(cache[dev] >> 20);
     return TMX_OK;
   }
   int cus = 0, per_cu = 0;
@@ -1036,7 +1391,9 @@ static int resident_workgroups(K kernel, unsigned* cache, long long* out) {
   TMX_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * kWaves, 0));
   if (per_cu < 1) per_cu = 1;
   *out = (long long)cus * per_cu;
-  if (dev >= 0 && dev < kMaxDevices) cache[dev] = (unsigned)*out;  // same value from every thread
+  *cus_out = cus;
+  // (resident workgroups, CUs) packed into one word: same value from every thread
+  if (dev >= 0 && dev < kMaxDevices && cus < 4096 && *out < (1 << 20)) cache[dev] = ((unsigned)cus << 20) | (unsigned)*out;
   return TMX_OK;
 }
 
@@ -1053,15 +1410,43 @@ static int persistent_grid(long long resident, const AttnParams& p, unsigned* gr
 }
 
 template <typename TR, int D, bool PAGED, bool HAS_BIAS>
-static int launch_attn(const AttnParams& p, hipStream_t s) {
+static int launch_attn(const AttnParams& p_in, hipStream_t s) {
   auto kernel = attn_kernel<TR, D, kRingSlots, PAGED, HAS_BIAS>;
   static unsigned resident_cache[kMaxDevices] = {0};  // per device: resident workgroups of this instantiation
   long long resident = 0;
-  int rc = resident_workgroups(kernel, resident_cache, &resident);
+  int cus = 0;
+  int rc = resident_workgroups(kernel, resident_cache, &resident, &cus);
   if (rc != TMX_OK) return rc;
+  AttnParams p = p_in;
   unsigned grid = 0;
-  rc = persistent_grid(resident, p, &grid);
-  if (rc != TMX_OK) return rc;
+  if (HAS_BIAS) p.band_on = 0;
+  if (p.band_on) {
+    // Work-list workgroups: one per unit of the split q-blocks' pieces (they also take the few unsplit
+    // q-blocks outside the canonical positions); band workgroups: runs of band_rl q-blocks per unit, about
+    // one run per CU -- with one piece per CU (the piece length the library advises) every workgroup of the
+    // launch is resident from the start, and a band workgroup streams beside a piece for its whole life
+    // (measured at 32k tokens, Qwen3-8B heads: runs of 32 q-blocks 166 us, 16: 172, 8: 188).
+    TMX_CHECK_SUPPORTED(resident >= p.Y, "tmx_attention: %d K/V head chunks need at least as many resident workgroups (%lld)",
+                        p.Y, resident);
+    long long want = (long long)(p.num_heavy > 4 ? p.num_heavy : 4) * p.Y;
+    if (want > resident) want = resident - resident % p.Y;
+    p.n_generic = (int)want;
+    int rl = (int)(((long long)p.num_qblocks * p.Y + cus - 1) / cus);
+    rl = rl < 4 ? 4 : (rl > 64 ? 64 : rl);
+#ifdef TMX_TUNING
+    if (const char* env = getenv("TMX_BAND_RL")) rl = atoi(env);
+    if (const char* env = getenv("TMX_EXP")) p.exp_mode = atoi(env);
+#endif
+    p.band_rl = rl;
+    const long long runs = ((long long)p.num_qblocks + rl - 1) / rl;
+    const long long total = want + runs * p.Y;
+    TMX_CHECK_SUPPORTED(total < (1ll << 31), "tmx_attention: too many workgroups");
+    grid = (unsigned)total;
+  } else {
+    rc = persistent_grid(resident, p, &grid);
+    if (rc != TMX_OK) return rc;
+    p.n_generic = (int)grid;
+  }
   kernel<<<grid, 64 * kWaves, 0, s>>>(p);
   TMX_CHECK_HIP(hipGetLastError());
   return TMX_OK;
@@ -1181,7 +1566,8 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.partial_ml = a->partial_ml;
   p.stamps = nullptr;
 #ifdef TMX_STAMPS
-  p.stamps = reinterpret_cast<unsigned long long*>(a->partial_ml);  // diagnostic build: stamps replace the partial sums
+  // diagnostic build: the stamps go to the second half of a (max, sum) buffer of at least 2^20 floats (tools/stamps.py)
+  p.stamps = reinterpret_cast<unsigned long long*>(a->partial_ml + (1 << 19));
 #endif
   const int64_t lim = 0x7FFFFFFF;
   TMX_CHECK_SUPPORTED(a->q_stride_t <= lim && a->q_stride_h <= lim && a->out_stride_t <= lim &&
@@ -1233,6 +1619,19 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.num_heavy = (int)(a->num_partials < a->num_items ? a->num_partials : a->num_items);
   p.sched_w = sched_light_per_piece(a, ix);
   p.units_total = (long long)a->num_items * p.Y;
+  // The band path (sparse q-blocks in canonical position on workgroups of their own) covers the default
+  // pattern's shape: a window of 17..32 keys below the row, at most 16 sink columns, four query heads per
+  // workgroup, 32-row q-blocks that the index does not split.
+  p.num_qblocks = (int)(a->num_items - a->num_partials + a->num_split_qblocks);
+  p.band_on = (a->mode == TMX_MODE_TRIANGLE && !has_bias && p.Gw == 4 && p.block_m == 32 && a->sl >= 17 && a->sl <= 32 &&
+               a->si >= -1 && a->si <= 15 && a->last >= 0 && ix->chunk_tiles >= 3 && p.num_qblocks >= 8 &&
+               !(a->flags & (TMX_ATTN_SHORT_QUERIES | TMX_ATTN_NO_BAND)))
+                  ? 1
+                  : 0;
+  if (p.band_on) p.sched_w = 0;
+  p.band_rl = 0;
+  p.n_generic = 0;
+  p.exp_mode = 0;
   hipStream_t s = (hipStream_t)stream;
   if (a->io_dtype == TMX_BF16) {
     if (a->head_dim == 128) return launch<Bf16Traits, 128>(p, paged, has_bias, a->num_split_qblocks, a->flags, s);
