@@ -261,6 +261,10 @@ typedef struct tmx_attention_args_t {
 /* Measurement aid: every q-block goes through the work list (the band workgroups that otherwise take the
  * sparse q-blocks in canonical position are not launched).  Results do not depend on it. */
 #define TMX_ATTN_NO_BAND 8u
+/* Measurement aid: a causal launch keeps every request on the work list (the dense causal kernel that
+ * otherwise computes the requests with 17 query rows or more is not launched).  Same results within the
+ * tolerance of the attention (the two kernels sum in different orders). */
+#define TMX_ATTN_NO_DENSE 16u
 
 int tmx_attention(const tmx_attention_args_t* args, void* stream);
 

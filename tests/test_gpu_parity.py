@@ -1145,3 +1145,37 @@ def test_band_path_matches_oracle_and_work_list(case):
     assert not np.isnan(got).any()
     assert np.all(np.abs(got - ref) <= tol), np.abs(got - ref).max()
     assert np.all(np.abs(plain - ref) <= tol), np.abs(plain - ref).max()
+
+
+@pytest.mark.parametrize("case", [
+    dict(q=[700], s=[700], H=8, Hkv=2),                                            # one prompt, ragged last block
+    dict(q=[300, 1, 17, 64, 5], s=[300, 900, 217, 64, 2000], H=8, Hkv=2, paged=True),  # prompts, decode rows, context
+    dict(q=[513, 130], s=[1999, 130], H=16, Hkv=2, paged=True, page=64, dtype=torch.float16),  # 8 heads per K/V head
+    dict(q=[1100], s=[1100], H=4, Hkv=1, out=torch.bfloat16),
+    dict(q=[200, 333], s=[200, 1333], H=4, Hkv=4, out=torch.float16, dtype=torch.float16),  # no grouping: work list only
+])
+def test_dense_causal_kernel_matches_oracle_and_work_list(case):
+    """Causal launches (the layers outside the triangle set): requests with 17 query rows or more run on the
+    dense kernel (32-row waves, 64-key tiles, fp16 probabilities against V converted to fp16), the others on
+    the work list; same results as the oracle and as the same launch kept on the work list (TMX_ATTN_NO_DENSE)."""
+    from vllm_trianglemix_amd._lib import TMX_ATTN_NO_DENSE
+    ops = _ops()
+    q_lens, seq_lens, H, Hkv, D = case["q"], case["s"], case["H"], case["Hkv"], 128
+    dtype, out_dtype = case.get("dtype", torch.bfloat16), case.get("out", torch.float32)
+    q, ks, vs = _rand_case(4711 + H, q_lens, seq_lens, H, Hkv, D)
+    if dtype == torch.float16:
+        q, ks, vs = (np.float16(q).astype(np.float32), [np.float16(k).astype(np.float32) for k in ks],
+                     [np.float16(v).astype(np.float32) for v in vs])
+    vs[0][3, 0, :8] = [40000.0, -3.0e-6, 2.0 ** -15, -65504.0 if dtype == torch.float16 else -65280.0, 1e-30, 0.0, 255.0, -0.001]
+    vs = [orc.bf16_round(v) if dtype == torch.bfloat16 else np.float16(v).astype(np.float32) for v in vs]
+    scale = D ** -0.5
+    kw = dict(dtype=dtype, out_dtype=out_dtype, paged=case.get("paged", False), page_size=case.get("page", 16), chunk=16)
+    got = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, "causal", (0, 0, 0), **kw)
+    plain = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, "causal", (0, 0, 0), flags=TMX_ATTN_NO_DENSE, **kw)
+    cu = np.concatenate([[0], np.cumsum(q_lens)])
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu, seq_lens, scale, "causal", 0, 0, 0)
+    # (the large V entries make |ref| large on a few rows: the bar is relative there)
+    tol = ATOL_F32_OUT * np.maximum(1.0, np.abs(ref)) + (np.abs(ref) * 2.0 ** -8 if out_dtype != torch.float32 else 0.0)
+    assert not np.isnan(got).any()
+    assert np.all(np.abs(got - ref) <= tol), np.abs(got - ref).max()
+    assert np.all(np.abs(plain - ref) <= tol), np.abs(plain - ref).max()

@@ -70,7 +70,7 @@ class AttentionArgs(Structure):
         ("flags", c_uint32), ("reserved", c_uint32),
     ]
 
-TMX_ATTN_SKIP_COMBINE, TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES, TMX_ATTN_NO_BAND = 1, 2, 4, 8
+TMX_ATTN_SKIP_COMBINE, TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES, TMX_ATTN_NO_BAND, TMX_ATTN_NO_DENSE = 1, 2, 4, 8, 16
 
 
 _lib = None

@@ -29,6 +29,7 @@
 // 16-byte pieces of a row, P needs no cross-lane movement between the two
 // products, and every lane ends with 8 consecutive output columns per store.
 #include "tmx_common.h"
+#include "tmx_dense.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -141,6 +142,7 @@ struct AttnParams {
   int band_rl;                // q-blocks per band workgroup
   int n_generic;              // workgroups 0 .. n_generic - 1 walk the work list, the others are band workgroups
   int num_qblocks;            // q-blocks of the batch
+  int dense_on;               // requests of kDenseMinRows query rows or more are computed by the dense causal kernel
   int exp_mode;               // tuning builds: 1 = work-list workgroups return at once, 2 = band workgroups do
   long long units_total;      // work items x Y
   int mode, si, sl, last, tri_min_len;
@@ -730,6 +732,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       if (!ok) return 0;
       a0 = sload(reinterpret_cast<const i32x4*>(p.items) + 2ll * item);
       a1 = sload(reinterpret_cast<const i32x4*>(p.items) + 2ll * item + 1);
+      if (p.dense_on) {
+        // causal launch with the dense kernel beside it: only the requests with few query rows are computed here
+        if (sload(p.cu_q + a1.x + 1) - sload(p.cu_q + a1.x) < kDenseMinRows) return 1;
+        continue;
+      }
       if (!p.band_on || a0.w >= 0) return 1;  // (pieces of split q-blocks never take the band path)
       const int nf = p.full_lens != nullptr ? imax(a1.w, sload(p.full_lens + a1.x)) : a1.w;
       if (!band_qblock(band_rule, a1.z, a1.w, nf)) return 1;
@@ -1323,6 +1330,7 @@ __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p
   const int q_start = p.cu_q[b];
   const int q_len = p.cu_q[b + 1] - q_start;
   if (row >= imin(p.block_m, q_len - row0)) return;
+  if (p.dense_on && q_len >= kDenseMinRows) return;  // the dense causal kernel wrote this request's rows
   const long long stride = (long long)p.H * p.block_m;  // partial rows between consecutive pieces
   const long long prow0 = ((long long)slot0 * p.H + head) * p.block_m + row;
   // pass 1 over the (max, sum) pairs: the common maximum; pass 2: weights, independent loads
@@ -1629,10 +1637,47 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
                   ? 1
                   : 0;
   if (p.band_on) p.sched_w = 0;
+  // Dense causal kernel: long requests of a causal launch (the layers outside the triangle set) go to the
+  // kernel built for the matrix cores; this launch keeps the requests with few query rows.
+  p.dense_on = (a->mode == TMX_MODE_CAUSAL && !has_bias && G % 4 == 0 && a->head_dim == 128 && a->batch <= kDenseMaxBatch &&
+                a->total_q >= kDenseMinRows && !(a->flags & (TMX_ATTN_SHORT_QUERIES | TMX_ATTN_NO_DENSE | TMX_ATTN_ONLY_COMBINE)))
+                   ? 1
+                   : 0;
   p.band_rl = 0;
   p.n_generic = 0;
   p.exp_mode = 0;
   hipStream_t s = (hipStream_t)stream;
+  if (p.dense_on) {
+    DenseParams d;
+    d.q = a->q;
+    d.out = a->out;
+    d.k = a->k;
+    d.v = a->v;
+    d.block_table = a->block_table;
+    d.cu_k = a->cu_seqlens_k;
+    d.cu_q = a->cu_seqlens_q;
+    d.seq_lens = a->seq_lens;
+    d.q_stride_t = p.q_stride_t;
+    d.q_stride_h = p.q_stride_h;
+    d.out_stride_t = p.out_stride_t;
+    d.out_stride_h = p.out_stride_h;
+    d.kv_stride_page = p.kv_stride_page;
+    d.kv_stride_t = p.kv_stride_t;
+    d.kv_stride_h = p.kv_stride_h;
+    d.block_table_stride = p.block_table_stride;
+    d.page_size = p.page_size;
+    d.page_shift = p.page_shift;
+    d.H = p.H;
+    d.Hkv = p.Hkv;
+    d.G = G;
+    d.Y = a->num_kv_heads * (G / 4);
+    d.batch = a->batch;
+    d.total_q = a->total_q;
+    d.out_dtype = a->out_dtype;
+    d.scale_log2 = p.scale_log2;
+    const int rc = launch_dense_causal(d, a->io_dtype == TMX_BF16, paged, s);
+    if (rc != TMX_OK) return rc;
+  }
   if (a->io_dtype == TMX_BF16) {
     if (a->head_dim == 128) return launch<Bf16Traits, 128>(p, paged, has_bias, a->num_split_qblocks, a->flags, s);
     return launch<Bf16Traits, 64>(p, paged, has_bias, a->num_split_qblocks, a->flags, s);

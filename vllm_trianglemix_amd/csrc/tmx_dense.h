@@ -1,0 +1,37 @@
+// Dense causal attention kernel (tmx_dense.hip): parameters and launcher, shared with the dispatch in
+// tmx_attention.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tmx {
+
+// Requests with at least this many query rows take the dense kernel; shorter ones (decode, speculative
+// decode) stay on the work-list kernel, whose 16-row waves waste nothing on them.
+constexpr int kDenseMinRows = 17;
+// The kernel keeps one block count per request in LDS.
+constexpr int kDenseMaxBatch = 512;
+
+struct DenseParams {
+  const void* q;
+  void* out;
+  const void* k;
+  const void* v;
+  const int32_t* block_table;
+  const int32_t* cu_k;
+  const int32_t* cu_q;
+  const int32_t* seq_lens;
+  int q_stride_t, q_stride_h, out_stride_t, out_stride_h;  // elements
+  int kv_stride_page, kv_stride_t, kv_stride_h, block_table_stride;
+  int page_size, page_shift;
+  int H, Hkv, G;   // G = H / Hkv, a multiple of 4
+  int Y;           // K/V head chunks: Hkv * G / 4
+  int batch, total_q;
+  int out_dtype;
+  float scale_log2;
+};
+
+int launch_dense_causal(const DenseParams& p, bool bf16, bool paged, hipStream_t s);
+
+}  // namespace tmx

@@ -1,0 +1,393 @@
+// Dense causal attention for gfx950 (MI355X): the layers outside the triangle set attend causally
+// (reference: the dense mask of vllm/attention/trianglemix_attention.py:200-219 behind the eager product of
+// vllm/attention/ascend_trianglemix.py:88-106), and a long prompt's causal attention is matrix-core bound:
+// N^2/2 pairs per head against N rows of K/V.  This kernel is shaped for the matrix cores, where the work-list
+// kernel (tmx_attention.hip) is shaped for sparse rows:
+//
+//   workgroup = 8 waves = 4 query heads of one K/V head x 64 query rows (two 32-row blocks); wave w owns
+//   32 rows of one head.  Key tiles of 64 keys, K and V staged once per workgroup in LDS (double buffered,
+//   fetched one tile ahead into registers, written after the tile's arithmetic).
+//   S^T[key][row] = K . Q^T with v_mfma_f32_32x32x16 (A = K rows from LDS by ds_read_b128 through an XOR
+//   swizzle, B = the wave's query rows kept in registers): a lane ends with 32 scores of ONE query row, so
+//   the softmax needs one cross-lane step (lane l and l ^ 32 share a row).
+//   O^T[d][row] += V^T . P^T, again 32x32x16: the score accumulators, converted to 16 bit in place, ARE the
+//   B operand (no LDS round trip); V^T comes out of LDS transposed (ds_read_b64_tr_b16).
+//   Per 64-key tile and wave: 32 matrix instructions of 32 cycles on 64 KB of operands read from LDS, against
+//   24 of 16 cycles on 16 KB in the work-list kernel's 16-row x 32-key step.
+//
+// Probabilities enter the second product as ONE 16-bit term.  bf16 has 8 significant bits, too few for the
+// 1e-3 bar (a peaked row's error is 2^-9 |v|), so for bf16 inputs V is converted to fp16 on its way into LDS
+// (exact for |v| <= 65504 down to 2^-14; smaller magnitudes keep an absolute error below 2^-25) and the
+// probabilities are fp16 (11 bits, rounded to nearest).  fp16 inputs need no conversion.
+//
+// Requests with fewer than kDenseMinRows query rows (decode, speculative decode) stay on the work-list kernel.
+#include "tmx_common.h"
+#include "tmx_dense.h"
+
+namespace tmx {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+constexpr int kDM = 64;        // query rows per workgroup
+constexpr int kDN = 64;        // keys per tile
+constexpr int kDRowB = 256;    // bytes per K / V row in LDS (head size 128, 16-bit)
+constexpr int kDTile = kDN * kDRowB;  // one tensor of one tile: 16 KB
+constexpr float kDMinusBig = -1.0e30f;
+constexpr float kDSlack = 8.0f;  // the running maximum moves only when a tile exceeds it by more than this (log2 units)
+
+template <typename T>
+__device__ __forceinline__ T dsload(const T* ptr) {
+  return *reinterpret_cast<const __attribute__((address_space(4))) T*>((const __attribute__((address_space(4))) void*)ptr);
+}
+
+template <bool BF16>
+__device__ __forceinline__ f32x16 mfma_qk(uint4 a, uint4 b, f32x16 c) {
+  if constexpr (BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_pv(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// two floats -> one dword of two fp16, round to nearest even
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, f16x2_t));
+}
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+// one dword of two bf16 -> one dword of two fp16 (exact inside fp16's range)
+__device__ __forceinline__ uint32_t bf16x2_to_f16x2(uint32_t w) {
+  return pack_f16(__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u));
+}
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ uint4 lds_b128(unsigned addr) {
+  return __builtin_bit_cast(uint4, *(const __attribute__((address_space(3))) u32x4_t*)(uintptr_t)addr);
+}
+__device__ __forceinline__ void lds_store_b128(unsigned addr, uint4 v) {
+  *(__attribute__((address_space(3))) u32x4_t*)(uintptr_t)addr = __builtin_bit_cast(u32x4_t, v);
+}
+__device__ __forceinline__ s16x4_t lds_tr16(unsigned addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)addr);
+}
+
+template <bool BF16, bool PAGED>
+__global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams p) {
+  __shared__ __attribute__((aligned(1024))) char lds[4 * kDTile];  // [buffer][K | V]
+  __shared__ int blk_ptr[kDenseMaxBatch + 1];                       // first 64-row block of every request
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int hg = wave & 3, rb = wave >> 2;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds));
+
+  // ---- the launch's work: 64-row blocks of the requests this kernel takes, x K/V head chunks ----
+  for (int b = tid; b < p.batch; b += 512) {
+    const int q_len = p.cu_q[b + 1] - p.cu_q[b];
+    blk_ptr[b + 1] = q_len >= kDenseMinRows ? (q_len + kDM - 1) / kDM : 0;
+  }
+  if (tid == 0) blk_ptr[0] = 0;
+  __syncthreads();
+  // inclusive scan of blk_ptr[1 .. batch] (batch <= 512: one element per thread)
+  for (int step = 1; step < p.batch; step <<= 1) {
+    int add = 0;
+    if (tid < p.batch && tid >= step) add = blk_ptr[tid + 1 - step];
+    __syncthreads();
+    if (tid < p.batch) blk_ptr[tid + 1] += add;
+    __syncthreads();
+  }
+  const int num_blocks = blk_ptr[p.batch];
+  const int lanes_per_unit = (int)gridDim.x / p.Y;  // workgroups that share a K/V head chunk (grid is a multiple of Y)
+  const int kvc = (int)blockIdx.x % p.Y;
+  const int wg_lane = (int)blockIdx.x / p.Y;
+  const int chunks = p.G / 4;
+  const int kvh = kvc / chunks;
+  const int head = kvh * p.G + (kvc - kvh * chunks) * 4 + hg;
+
+  // ---- per-lane constants ----
+  // K fragment (A of S^T = K Q^T): key row 32 kb + r, 16-byte chunk 2 ks + h, stored at chunk ^ (row & 15)
+  int koff[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) koff[ks] = r * kDRowB + 16 * ((2 * ks + h) ^ (r & 15));
+  // V^T fragment (A of O^T = V^T P^T): two transposed 4-key x 16-column blocks; lane 4 q + pp of a 16-lane group
+  // addresses key row q of the block, columns 4 pp .. 4 pp + 3 of the group's 16; chunk index ^ ((key & 3) << 2)
+  const int tq = (lane & 15) >> 2, tpp = lane & 3, dhalf = (lane >> 4) & 1;
+  int voff[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    voff[db] = kDTile + (4 * h + tq) * kDRowB + 16 * ((((db ^ tq) << 2)) | (2 * dhalf + (tpp >> 1))) + 8 * (tpp & 1);
+  // staging: thread t carries 32 bytes (chunks 2 c2, 2 c2 + 1) of key row t / 8 of K and of V
+  const int srow = tid >> 3, sc2 = tid & 7;
+  const unsigned st_k0 = srow * kDRowB + 16 * ((2 * sc2) ^ (srow & 15));
+  const unsigned st_k1 = srow * kDRowB + 16 * ((2 * sc2 + 1) ^ (srow & 15));
+  const unsigned st_v0 = kDTile + srow * kDRowB + 16 * ((2 * sc2) ^ ((srow & 3) << 2));
+  const unsigned st_v1 = kDTile + srow * kDRowB + 16 * ((2 * sc2 + 1) ^ ((srow & 3) << 2));
+  const int kv_row_bytes = 2 * p.kv_stride_t;
+  const char* const k_head = reinterpret_cast<const char*>(p.k) + 2ll * kvh * p.kv_stride_h + 32 * sc2;
+  const char* const v_head = reinterpret_cast<const char*>(p.v) + 2ll * kvh * p.kv_stride_h + 32 * sc2;
+
+  const int rounds = (num_blocks + lanes_per_unit - 1) / lanes_per_unit;
+#pragma unroll 1
+  for (int round = 0; round < rounds; ++round) {
+    // blocks in descending length within a request; odd rounds run the workgroups backwards, so that every
+    // workgroup's sum of block lengths comes out about equal
+    const int ord = round * lanes_per_unit + ((round & 1) ? lanes_per_unit - 1 - wg_lane : wg_lane);
+    if (ord >= num_blocks) continue;
+    // request of block `ord`: the last b with blk_ptr[b] <= ord
+    int lo = 0, hi = p.batch;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (blk_ptr[mid] <= ord) lo = mid;
+      else hi = mid;
+    }
+    const int b = __builtin_amdgcn_readfirstlane(lo);
+    const int nb = blk_ptr[b + 1] - blk_ptr[b];
+    const int blk = __builtin_amdgcn_readfirstlane(nb - 1 - (ord - blk_ptr[b]));
+    const int q_start = dsload(p.cu_q + b);
+    const int q_len = dsload(p.cu_q + b + 1) - q_start;
+    const int n = dsload(p.seq_lens + b);
+    const int ctx = n - q_len;
+    const int r0 = kDM * blk;
+    const int rows_valid = imin(kDM, q_len - r0);
+    const int w_r0 = r0 + 32 * rb;                       // first row of this wave
+    const bool w_rows = 32 * rb < rows_valid;             // the wave has rows at all
+    const int my_row = imin(w_r0 + r, q_len - 1);         // (rows past the end compute on a valid row, unstored)
+    const bool row_ok = w_r0 + r < q_len;
+    const int pos = ctx + my_row;                          // this lane's query position
+    const int w_pos0 = ctx + w_r0;                         // smallest position of the wave
+    const int num_tiles = (ctx + r0 + rows_valid - 1) / kDN + 1;
+    const int w_tiles = w_rows ? (ctx + imin(w_r0 + 31, q_len - 1)) / kDN + 1 : 0;  // tiles this wave needs
+
+    // ---- query rows of the wave: B operand fragments, chunk 2 ks + h of row r ----
+    uint4 qf[8];
+    {
+      const char* qrow = reinterpret_cast<const char*>(p.q) + 2ll * ((long long)(q_start + my_row) * p.q_stride_t + (long long)head * p.q_stride_h) + 16 * h;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qrow + 32 * ks);
+    }
+
+    const long long krow0 = PAGED ? 0 : (long long)dsload(p.cu_k + b);
+    const int32_t* const bt = PAGED ? p.block_table + (long long)b * p.block_table_stride : nullptr;
+    // this thread's 32 bytes of K and of V of tile t (keys past the end read the last key: masked later)
+    auto fetch = [&](int t, uint4 (&kreg)[2], uint4 (&vreg)[2]) {
+      const int key_w = imin(kDN * t + 8 * wave, n - 1);     // the wave's first key (its 8 keys share a page)
+      const int key = imin(kDN * t + srow, n - 1);
+      long long off;
+      if constexpr (PAGED) {
+        const long long pg = dsload(bt + (key_w >> p.page_shift));
+        off = 2ll * pg * p.kv_stride_page + (long long)(key & (p.page_size - 1)) * kv_row_bytes;
+      } else {
+        off = (krow0 + key) * kv_row_bytes;
+      }
+      kreg[0] = *reinterpret_cast<const uint4*>(k_head + off);
+      kreg[1] = *reinterpret_cast<const uint4*>(k_head + off + 16);
+      vreg[0] = *reinterpret_cast<const uint4*>(v_head + off);
+      vreg[1] = *reinterpret_cast<const uint4*>(v_head + off + 16);
+    };
+    auto stage = [&](unsigned buf, const uint4 (&kreg)[2], uint4 (&vreg)[2]) {
+      if constexpr (BF16) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          vreg[x].x = bf16x2_to_f16x2(vreg[x].x);
+          vreg[x].y = bf16x2_to_f16x2(vreg[x].y);
+          vreg[x].z = bf16x2_to_f16x2(vreg[x].z);
+          vreg[x].w = bf16x2_to_f16x2(vreg[x].w);
+        }
+      }
+      lds_store_b128(buf + st_k0, kreg[0]);
+      lds_store_b128(buf + st_k1, kreg[1]);
+      lds_store_b128(buf + st_v0, vreg[0]);
+      lds_store_b128(buf + st_v1, vreg[1]);
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[db][i] = 0.f;
+    float m_run = kDMinusBig, l_run = 0.f;
+
+    // every wave is done with the previous block's tiles
+    __syncthreads();
+    {
+      uint4 kreg[2], vreg[2];
+      fetch(0, kreg, vreg);
+      stage(lds_base, kreg, vreg);
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int t = 0; t < num_tiles; ++t) {
+      const unsigned cur = lds_base + (unsigned)(t & 1) * 2 * kDTile;
+      const unsigned nxt = lds_base + (unsigned)((t + 1) & 1) * 2 * kDTile;
+      uint4 kreg[2], vreg[2];
+      const bool more = t + 1 < num_tiles;
+      if (more) fetch(t + 1, kreg, vreg);
+
+      if (t < w_tiles) {
+        // ---- S^T = K Q^T: two 32-key blocks ----
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) s[kb] = mfma_qk<BF16>(lds_b128(cur + koff[ks] + kb * 32 * kDRowB), qf[ks], s[kb]);
+        }
+        // register i of block kb is key 64 t + 32 kb + (i & 3) + 8 (i >> 2) + 4 h
+        const int key0 = kDN * t + 4 * h;
+        if (kDN * t + kDN - 1 > w_pos0) {  // the tile reaches past some row's diagonal
+          const int d = pos - key0;        // attended iff key offset <= d
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+              s[kb][i] = (32 * kb + (i & 3) + 8 * (i >> 2) <= d) ? s[kb][i] : -__builtin_inff();
+        }
+        float tmax = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[kb][i]);
+        // the running maximum moves only when some row's tile maximum exceeds it by more than the slack:
+        // the usual tile has no cross-lane step and no pass over the accumulators
+        if (__builtin_amdgcn_ballot_w64(tmax * p.scale_log2 > m_run + kDSlack) != 0) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+          tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+          const float m_tile = tmax * p.scale_log2;
+          const float m_new = (m_tile > m_run + kDSlack) ? m_tile : m_run;
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+          l_run *= alpha;
+          if (t > 0) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) acc[db] *= alpha;
+          }
+        }
+        // probabilities, 16 bit in place: registers 8 u .. 8 u + 7 of block kb are the B fragment of k-step u
+        uint4 pf[2][2];
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * u + j], p.scale_log2, -m_run));
+              const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * u + j + 1], p.scale_log2, -m_run));
+              psum += p0 + p1;
+              w[j >> 1] = pack_f16(p0, p1);
+            }
+            pf[kb][u] = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        l_run += psum;
+        // ---- O^T += V^T P^T: element j of lane half h in k-step u of block kb is key 32 kb + 16 u + 8 (j >> 2) + 4 h + (j & 3) ----
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const unsigned vb = cur + (32 * kb + 16 * u) * kDRowB;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+              const s16x4_t lo4 = lds_tr16(vb + voff[db]);
+              const s16x4_t hi4 = lds_tr16(vb + voff[db] + 8 * kDRowB);
+              const uint4 vf = __builtin_bit_cast(uint4, (s16x8_t)__builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+              acc[db] = mfma_pv(vf, pf[kb][u], acc[db]);
+            }
+          }
+      }
+
+      if (more) stage(nxt, kreg, vreg);
+      __syncthreads();
+    }
+
+    // ---- epilogue: lane (row r, half h) holds columns 32 db + 8 e + 4 h .. + 3 in registers 4 e .. 4 e + 3 of acc[db] ----
+    if (w_rows) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+      const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      const float inv = 1.0f / l_tot;
+      const long long orow = (long long)(q_start + my_row) * p.out_stride_t + (long long)head * p.out_stride_h;
+      if (p.out_dtype == TMX_F32) {
+        float* po = reinterpret_cast<float*>(p.out) + orow + 4 * h;
+        if (row_ok) {
+#pragma unroll
+          for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              *reinterpret_cast<float4*>(po + 32 * db + 8 * e) =
+                  make_float4(acc[db][4 * e] * inv, acc[db][4 * e + 1] * inv, acc[db][4 * e + 2] * inv, acc[db][4 * e + 3] * inv);
+        }
+      } else {
+        // 16-bit output: lanes l and l ^ 32 exchange 8-byte pieces so that every lane stores 16 contiguous bytes:
+        // of a pair of column groups (e, e + 1) the lower half-wave ends with all 8 columns of group e, the upper
+        // half-wave with those of group e + 1
+        uint16_t* po = reinterpret_cast<uint16_t*>(p.out) + orow;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            uint32_t a0, a1, b0, b1;
+            if (p.out_dtype == TMX_BF16) {
+              a0 = pack_bf16(acc[db][4 * e] * inv, acc[db][4 * e + 1] * inv);
+              a1 = pack_bf16(acc[db][4 * e + 2] * inv, acc[db][4 * e + 3] * inv);
+              b0 = pack_bf16(acc[db][4 * e + 4] * inv, acc[db][4 * e + 5] * inv);
+              b1 = pack_bf16(acc[db][4 * e + 6] * inv, acc[db][4 * e + 7] * inv);
+            } else {
+              a0 = pack_f16(acc[db][4 * e] * inv, acc[db][4 * e + 1] * inv);
+              a1 = pack_f16(acc[db][4 * e + 2] * inv, acc[db][4 * e + 3] * inv);
+              b0 = pack_f16(acc[db][4 * e + 4] * inv, acc[db][4 * e + 5] * inv);
+              b1 = pack_f16(acc[db][4 * e + 6] * inv, acc[db][4 * e + 7] * inv);
+            }
+            // swap: the upper half-wave's a with the lower half-wave's b
+            const auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            // lower half: (own a, partner's a) = columns 0..3 | 4..7 of group e; upper half: (partner's b, own b) of group e + 1
+            if (row_ok)
+              *reinterpret_cast<uint4*>(po + 32 * db + 8 * (e + h)) = make_uint4(x0[0], x1[0], x0[1], x1[1]);
+          }
+      }
+    }
+  }
+}
+
+}  // namespace tmx
+
+namespace tmx {
+
+int launch_dense_causal(const DenseParams& p, bool bf16, bool paged, hipStream_t s) {
+  static unsigned cus_cache[64] = {0};
+  int dev = 0;
+  TMX_CHECK_HIP(hipGetDevice(&dev));
+  int cus = (dev >= 0 && dev < 64) ? (int)cus_cache[dev] : 0;
+  if (cus == 0) {
+    TMX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < 64) cus_cache[dev] = (unsigned)cus;
+  }
+  // one workgroup per CU (the registers of 8 waves x 256 fill a CU), a multiple of the K/V head chunks, and no
+  // more workgroups than there are (64-row block, chunk) units at most
+  long long grid = cus - cus % p.Y;
+  if (grid < p.Y) grid = p.Y;
+  const long long units = ((long long)p.total_q / kDM + p.batch) * p.Y;  // upper bound of the blocks x chunks
+  if (grid > units) grid = units - units % p.Y;
+  if (grid < p.Y) grid = p.Y;
+  if (bf16) {
+    if (paged) dense_causal_kernel<true, true><<<(unsigned)grid, 512, 0, s>>>(p);
+    else dense_causal_kernel<true, false><<<(unsigned)grid, 512, 0, s>>>(p);
+  } else {
+    if (paged) dense_causal_kernel<false, true><<<(unsigned)grid, 512, 0, s>>>(p);
+    else dense_causal_kernel<false, false><<<(unsigned)grid, 512, 0, s>>>(p);
+  }
+  TMX_CHECK_HIP(hipGetLastError());
+  return TMX_OK;
+}
+
+}  // namespace tmx
