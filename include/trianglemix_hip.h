@@ -222,6 +222,13 @@ typedef struct tmx_attention_args_t {
   int64_t block_table_stride;
   int32_t page_size;
   const int32_t* cu_seqlens_k; /* (device) [batch + 1], contiguous mode only */
+  /* K/V element type: 0 (or io_dtype) = the 16-bit type of q; TMX_FP8_E4M3 = an fp8 (e4m3fn) paged cache as
+   * tmx_reshape_and_cache_fp8 writes it (kv_cache_dtype "fp8"): strides then count bytes, and the kernel
+   * reads value = fp8 x k_scale / v_scale, rounded once to the 16-bit type, inside its tile loop (the
+   * k_descale / v_descale of vllm/v1/attention/backends/rocm_attn.py:421-422).  Paged layout, head_dim 128,
+   * no bias. */
+  int32_t kv_dtype;
+  float k_scale, v_scale;
 
   const int32_t* cu_seqlens_q; /* (device) [batch + 1] */
   const int32_t* seq_lens;     /* (device) [batch] */

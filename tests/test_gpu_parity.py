@@ -1179,3 +1179,60 @@ def test_dense_causal_kernel_matches_oracle_and_work_list(case):
     assert not np.isnan(got).any()
     assert np.all(np.abs(got - ref) <= tol), np.abs(got - ref).max()
     assert np.all(np.abs(plain - ref) <= tol), np.abs(plain - ref).max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("page", [16, 64])
+def test_fp8_cache_read_in_place(dtype, page):
+    """fp8 (e4m3fn) paged K/V read by the attention kernel itself (head size 128): the kernel's conversion stage
+    produces value = fp8 x scale rounded once to the 16-bit type, exactly what the gather pass produces, so the
+    results must agree with the oracle on the dequantised values -- triangle prompts with dense trailing rows,
+    a causal launch, decode rows with the short-queries hint, ragged lengths, non-power-of-two scales."""
+    ops = _ops()
+    H, Hkv, D = 8, 2, 128
+    k_scale, v_scale = 0.75, 1.5
+    scale = D ** -0.5
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else (lambda x: np.float16(x).astype(np.float32))
+    for mode, pat, q_lens, seq_lens, flags in (
+            ("triangle", (4, 32, 64), [2300, 70, 1], [2300, 2500, 333], 0),
+            ("causal", (0, 0, 0), [130, 1, 40], [130, 1000, 77], 0),
+            ("triangle", (4, 32, 64), [1, 1, 1, 1], [5000, 31, 32, 2049], TMX_ATTN_SHORT_QUERIES)):
+        q, ks, vs = _rand_case(1234 + page, q_lens, seq_lens, H, Hkv, D)
+        q = rnd(q)
+        ks[0][5, 0, :4] = [1000.0, -1000.0, 336.1, 1e-4]
+        B = len(seq_lens)
+        nblk = sum((s + page - 1) // page for s in seq_lens) + 2
+        perm = np.random.default_rng(7).permutation(nblk).astype(np.int32)
+        kc = torch.zeros((nblk, page, Hkv, D), dtype=torch.uint8, device=DEV)
+        vc = torch.zeros_like(kc)
+        bt = np.zeros((B, max((s + page - 1) // page for s in seq_lens)), np.int32)
+        nxt = 0
+        for b, s in enumerate(seq_lens):
+            for pb in range((s + page - 1) // page):
+                bt[b, pb] = perm[nxt]
+                nxt += 1
+            pos = np.arange(s)
+            slots = torch.from_numpy(bt[b, pos // page].astype(np.int64) * page + pos % page).to(DEV)
+            ops.reshape_and_cache_fp8(_to_dev(ks[b], dtype), _to_dev(vs[b], dtype), kc, vc, slots, k_scale, v_scale)
+        btd = torch.from_numpy(bt).to(DEV)
+        bm = ops.attention_block_m(H, Hkv)
+        for resolve in (True, False):  # pages resolved by the index builder, or looked up by the kernel
+            idx, cu, sld = _build(ops, q_lens, seq_lens, *pat, bm, 32, ops.MODES[mode], 8, 2048 if mode == "triangle" else 0,
+                                  block_table=btd if resolve else None, page_size=page)
+            out = torch.full((sum(q_lens), H, D), float("nan"), dtype=torch.float32, device=DEV)
+            ops.attention(_to_dev(q, dtype), kc.view(torch.float8_e4m3fn), vc.view(torch.float8_e4m3fn), out, idx, cu, sld,
+                          scale, block_table=btd, flags=flags, k_scale=k_scale, v_scale=v_scale)
+            torch.cuda.synchronize()
+            seen = lambda x, sc: rnd(orc.fp8_cache_roundtrip(rnd(x), sc).astype(np.float32))
+            kd, vd = [seen(k, k_scale) for k in ks], [seen(v, v_scale) for v in vs]
+            cu_h = np.concatenate([[0], np.cumsum(q_lens)])
+            ref = orc.varlen_gqa_attention(q, lambda b: kd[b], lambda b: vd[b], cu_h, seq_lens, scale, mode, *pat,
+                                           tri_min_len=2048 if mode == "triangle" else 0)
+            got = out.cpu().numpy()
+            assert not np.isnan(got).any()
+            assert np.abs(got - ref).max() <= ATOL_F32_OUT, (mode, resolve, np.abs(got - ref).max())
+    with pytest.raises(RuntimeError):  # no in-place path for other head sizes
+        q64 = torch.zeros((4, 2, 64), dtype=dtype, device=DEV)
+        ops.attention(q64, torch.zeros((2, page, 2, 64), dtype=torch.uint8, device=DEV),
+                      torch.zeros((2, page, 2, 64), dtype=torch.uint8, device=DEV), torch.empty_like(q64), idx, cu, sld,
+                      1.0, block_table=btd)

@@ -60,7 +60,8 @@ class AttentionArgs(Structure):
         ("k", c_void_p), ("v", c_void_p),
         ("kv_stride_page", c_int64), ("kv_stride_t", c_int64), ("kv_stride_h", c_int64),
         ("block_table", c_void_p), ("block_table_stride", c_int64), ("page_size", c_int32),
-        ("cu_seqlens_k", c_void_p), ("cu_seqlens_q", c_void_p), ("seq_lens", c_void_p),
+        ("cu_seqlens_k", c_void_p), ("kv_dtype", c_int32), ("k_scale", c_float), ("v_scale", c_float),
+        ("cu_seqlens_q", c_void_p), ("seq_lens", c_void_p),
         ("bias", c_void_p), ("bias_dtype", c_int32), ("bias_stride", c_int64),
         ("bias_rows", c_int32), ("bias_cols", c_int32),
         ("index", POINTER(Index)),

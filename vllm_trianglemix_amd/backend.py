@@ -131,6 +131,16 @@ class TriangleMixAttentionMetadata:
             self.__dict__["_whole_prompts"] = w
         return w
 
+    def fp8_row_offsets(self, device):
+        """Row offsets of every request's keys in a contiguous copy of the step's K/V (``cu_seqlens_k``), on the
+        device, and their total: made once per step, shared by the layers."""
+        hit = self.__dict__.get("_fp8_rows")
+        if hit is None:
+            cu_k_cpu = np.concatenate([[0], np.cumsum(self.seq_lens_cpu, dtype=np.int64)]).astype(np.int32)
+            hit = (torch.from_numpy(cu_k_cpu).to(device, non_blocking=True), int(cu_k_cpu[-1]))
+            self.__dict__["_fp8_rows"] = hit
+        return hit
+
     def workspace(self, idx: "ops.BlockIndex", num_heads: int, head_size: int, device) -> tuple:
         key = (id(idx), num_heads, head_size)
         ws = self._workspaces.get(key)
@@ -357,25 +367,30 @@ class TriangleMixAttentionImpl(_ImplBase):
     def _forward_fp8_cache(self, layer, q, key, value, key_cache, value_cache, m, output):
         """kv_cache_dtype "fp8" (rocm_attn.py:356-358, 421-422): the step's rows are written as
         fp8(x / scale); the attention then reads what the cache holds, times the scale.  The query
-        stays 16-bit, as on ROCm in the reference (rocm_attn.py:362-365).  The descale runs ahead of the
-        attention kernel into contiguous 16-bit rows kept for the step."""
+        stays 16-bit, as on ROCm in the reference (rocm_attn.py:362-365).  With head size 128 the attention
+        kernel descales inside its tile loop; other head sizes go through a descale pass into 16-bit rows."""
         n_tok = m.num_actual_tokens
         k_scale = float(getattr(layer, "_k_scale_float", 1.0))
         v_scale = float(getattr(layer, "_v_scale_float", 1.0))
         if self.kv_sharing_target_layer_name is None and key is not None and value is not None:
             ops.reshape_and_cache_fp8(key[:n_tok], value[:n_tok], key_cache, value_cache, m.slot_mapping[:n_tok],
                                       k_scale, v_scale)
-        cu_k_cpu = np.concatenate([[0], np.cumsum(m.seq_lens_cpu, dtype=np.int64)]).astype(np.int32)
-        cu_k = torch.from_numpy(cu_k_cpu).to(q.device, non_blocking=True)
-        k_rows, v_rows = ops.gather_dequant_kv_fp8(key_cache, value_cache, m.block_table, m.seq_lens, cu_k,
-                                                   int(cu_k_cpu[-1]), int(m.max_seq_len), q.dtype, k_scale, v_scale)
         out = output.view(-1, self.num_heads, self.head_size)[:n_tok]
         mode = "triangle" if self.use_triangle else "causal"
         pattern = self.pattern if self.use_triangle else (0, 0, 0)
         tri_min_len = self.tri_min_len if self.use_triangle else 0
         idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len)
         ws = m.workspace(idx, self.num_heads, self.head_size, q.device)
+        if self.head_size == 128:
+            # the attention kernel reads the fp8 pages in place and descales inside its tile loop
+            ops.attention(q, key_cache, value_cache, out, idx, m.query_start_loc, m.seq_lens, self.scale,
+                          block_table=m.block_table, workspace=ws, flags=_step_flags(m), k_scale=k_scale,
+                          v_scale=v_scale)
+            return output
+        # other head sizes: descale ahead of the kernel into contiguous 16-bit rows kept for the step
+        cu_k, total = m.fp8_row_offsets(q.device)
+        k_rows, v_rows = ops.gather_dequant_kv_fp8(key_cache, value_cache, m.block_table, m.seq_lens, cu_k,
+                                                   total, int(m.max_seq_len), q.dtype, k_scale, v_scale)
         ops.attention(q, k_rows, v_rows, out, idx, m.query_start_loc, m.seq_lens, self.scale, cu_seqlens_k=cu_k,
                       workspace=ws, flags=_step_flags(m))
         return output
-

@@ -148,6 +148,7 @@ struct AttnParams {
   int mode, si, sl, last, tri_min_len;
   int bias_rows, bias_cols, bias_dtype, out_dtype;
   float scale_log2;
+  float k_scale, v_scale;     // fp8 K/V cache: value = fp8 x scale
 };
 
 // Read through the scalar (constant) path: the index, the block table and the
@@ -603,19 +604,30 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
 // rows of a wave are read by that wave alone, so they go through a private LDS
 // region per wave with no workgroup synchronisation: the rows of item k + 1 are
 // fetched as soon as the fragments of item k sit in registers.
-template <typename TR, int D, int NS, bool PAGED, bool HAS_BIAS>
+// FP8: K and V are an fp8 (e4m3fn) paged cache.  The ring then holds the tiles as they are in memory (half the
+// bytes, NS = 4 entries), and every tile step opens with a conversion stage: the eight waves turn the entry of
+// the step, one 1-KiB piece each, into the 16-bit image the arithmetic reads (value x scale, rounded once to
+// the 16-bit type: the descale of the reference's attention kernels, vllm/v1/attention/backends/rocm_attn.py:421-422),
+// with a second barrier between the conversion and the arithmetic.
+template <typename TR, int D, int NS, bool PAGED, bool HAS_BIAS, bool FP8>
 __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p) {
   constexpr int KS = D / 32;            // k-steps of S^T = K Q^T
   constexpr int DB = D / 16;            // 16-column output blocks
-  constexpr int ROWB = D * 2;           // bytes per Q/K/V row in LDS
-  constexpr int CPR = D / 8;            // 16-byte chunks per row
-  constexpr int ENTRY = 64 * ROWB;      // ring entry: K tile + V tile
-  constexpr int HALF = ENTRY / 2;
+  constexpr int ROWB = D * 2;           // bytes per Q row, and per K/V row of the 16-bit image the arithmetic reads
+  constexpr int CPR = D / 8;            // 16-byte chunks per such row
+  constexpr int KVB = FP8 ? 1 : 2;      // bytes per K/V element in memory and in the ring
+  constexpr int KROWB = D * KVB;        // bytes per K/V row in the ring
+  constexpr int KCPR = KROWB / 16;
+  constexpr int ENTRY = 64 * KROWB;     // ring entry: K tile + V tile
+  constexpr int HALF = 32 * ROWB;       // V part of the 16-bit image of a tile
+  constexpr int IMG = FP8 ? 64 * ROWB : 0;  // fp8: the image of the entry being computed, behind the ring
   constexpr int QREG = 16 * ROWB;       // a wave's private region: its 16 Q rows
   constexpr int QP = QREG / 1024;       // LDS-DMA pieces of that region
-  constexpr int RPP = 1024 / ROWB;      // rows per 1-KiB LDS-DMA piece (one wave instruction)
+  constexpr int RPP = 1024 / ROWB;      // Q rows per 1-KiB LDS-DMA piece (one wave instruction)
+  constexpr int KRPP = 1024 / KROWB;    // K/V rows per piece
   constexpr int PE = ENTRY / 1024;      // pieces per entry
   constexpr int PT = PE / 2;            // ... per tensor of a K/V entry
+  static_assert(!FP8 || (D == 128 && PAGED && !HAS_BIAS), "fp8 K/V: paged cache, head size 128");
   // kIssuers waves fetch the K/V entries (and run the scalar walk that finds them); the others only meet them
   // at the barrier.  Waves 0..3 by default (measured 4-5 % faster on prefill than 4..7); waves 4..7 when the
   // caller says that no request has more than 16 query rows (decode): they own rows 16..31 of a q-block and
@@ -627,7 +639,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   static_assert(PW >= 1 && NS >= 3, "ring too small");
   using frag = typename TR::frag;
 
-  __shared__ __attribute__((aligned(1024))) char lds[NS * ENTRY + kWaves * QREG];
+  __shared__ __attribute__((aligned(1024))) char lds[NS * ENTRY + IMG + kWaves * QREG];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -639,7 +651,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   // of sparse q-blocks in canonical position (band_body).  One launch, so that the arithmetic-bound pieces of
   // the dense rows and the memory-bound sparse q-blocks share the CUs.
   const int bid = (int)blockIdx.x, ngrid = p.n_generic;
-  if constexpr (!HAS_BIAS) {
+  if constexpr (!HAS_BIAS && !FP8) {
     if (bid >= ngrid) {
 #ifdef TMX_TUNING
       if (p.exp_mode == 2) return;
@@ -664,7 +676,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   const int item0 = bid / p.Y;
   const int item_step = ngrid / p.Y;
 
-  const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = 2 * p.kv_stride_t;
+  const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = KVB * p.kv_stride_t;
 
   // ---- LDS-DMA issue: wave-uniform bases + per-lane constant byte offsets ----
   // Issuing wave w fetches pieces w * PW .. + PW - 1 of every K/V entry (one 16-key half of K or
@@ -675,16 +687,18 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   const int pi0 = (wave % kIssuers) * PW;
   const bool iss_v = pi0 >= PT;
   const int pit0 = pi0 % PT;
-  const bool iss_second = pit0 * RPP >= 16;  // keys 16..31 of the tile
+  const bool iss_second = pit0 * KRPP >= 16;  // keys 16..31 of the tile
   const char* const kv_iss =
-      reinterpret_cast<const char*>(iss_v ? p.v : p.k) + 2ll * kvh * p.kv_stride_h;
+      reinterpret_cast<const char*>(iss_v ? p.v : p.k) + (long long)KVB * kvh * p.kv_stride_h;
   const char* const q_own = reinterpret_cast<const char*>(p.q) + 2ll * head * p.q_stride_h;
-  const unsigned q_lds = lds_base + NS * ENTRY + wave * QREG;
+  const unsigned q_lds = lds_base + NS * ENTRY + IMG + wave * QREG;
   int kv_voff[PW], q_voff[QP];
 #pragma unroll
   for (int x = 0; x < PW; ++x) {
-    const int row = (pit0 + x) * RPP + piece_row;
-    kv_voff[x] = row * kv_row_bytes + 16 * (piece_cc ^ (iss_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row)));
+    const int row = (pit0 + x) * KRPP + lane / KCPR;
+    // (the 16-bit images are chunk-swizzled on their way in; fp8 tiles land as they are)
+    const int swz = FP8 ? 0 : (iss_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row));
+    kv_voff[x] = row * kv_row_bytes + 16 * ((lane % KCPR) ^ swz);
   }
 #pragma unroll
   for (int x = 0; x < QP; ++x) {
@@ -786,13 +800,13 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     d_tile = sload(p.col_idx + pos);
     if constexpr (PAGED) {
       if (p.tile_pages != nullptr) {
-        d_off0 = 2ll * sload(p.tile_pages + 2 * pos) * p.kv_stride_page;
-        d_off1 = 2ll * sload(p.tile_pages + 2 * pos + 1) * p.kv_stride_page;
+        d_off0 = (long long)KVB * sload(p.tile_pages + 2 * pos) * p.kv_stride_page;
+        d_off1 = (long long)KVB * sload(p.tile_pages + 2 * pos + 1) * p.kv_stride_page;
       } else {
         const int32_t* bt = p.block_table + (long long)i_b * p.block_table_stride;
         const int pg_first = (d_tile * kBlockN) >> p.page_shift;
-        d_off0 = 2ll * sload(bt + pg_first) * p.kv_stride_page;
-        d_off1 = 2ll * sload(bt + (imin(d_tile * kBlockN + 16, i_n - 1) >> p.page_shift)) * p.kv_stride_page;
+        d_off0 = (long long)KVB * sload(bt + pg_first) * p.kv_stride_page;
+        d_off1 = (long long)KVB * sload(bt + (imin(d_tile * kBlockN + 16, i_n - 1) >> p.page_shift)) * p.kv_stride_page;
       }
     }
   };
@@ -818,7 +832,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         const int l2 = opaque(lane);
 #pragma unroll
         for (int x = 0; x < PW; ++x) {
-          const int row = (pit0 + x) * RPP + l2 / CPR;
+          const int row = (pit0 + x) * KRPP + l2 / KCPR;
           const int j = imin(j0 + row, n - 1);
           long long off;
           if constexpr (PAGED) {
@@ -827,8 +841,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
           } else {
             off = (i_krow0 + j) * kv_row_bytes;
           }
-          const int swz = iss_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row);
-          glds16(kv_iss + off + 16 * ((l2 % CPR) ^ swz), dst + x * 1024);
+          const int swz = FP8 ? 0 : (iss_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row));
+          glds16(kv_iss + off + 16 * ((l2 % KCPR) ^ swz), dst + x * 1024);
         }
       }
     }
@@ -885,6 +899,31 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     if (issuer) {
 #pragma unroll 1
       while (i_src != 2 && gi - gs < NS) issue_one();
+    }
+    if constexpr (FP8) {
+      // Conversion stage: wave w turns piece w of the entry (8 rows of K for w < 4, of V for w >= 4; a lane
+      // 16 values of one row) into the 16-bit image, chunk-swizzled as the arithmetic reads it.  Every wave
+      // is past the barrier above, so nobody reads the previous tile's image any more.
+      const uint4 raw = lds_read_b128<uint4>(lds_base + (unsigned)gs_slot * ENTRY + wave * 1024 + lane * 16);
+      const bool cv = wave >= 4;
+      const int crow = 8 * (wave & 3) + (lane >> 3), cc = lane & 7;
+      const float sc = cv ? p.v_scale : p.k_scale;
+      const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+      uint32_t o[8];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)rw[x], false);
+        const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)rw[x], true);
+        o[2 * x] = TR::cvt2(lo[0] * sc, lo[1] * sc);
+        o[2 * x + 1] = TR::cvt2(hi[0] * sc, hi[1] * sc);
+      }
+      const int swz = cv ? v_chunk_swizzle<D>(crow) : k_chunk_swizzle<D>(crow);
+      const unsigned img = lds_base + NS * ENTRY + (cv ? HALF : 0) + crow * ROWB;
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(img + 16 * ((2 * cc) ^ swz)) = u32x4{o[0], o[1], o[2], o[3]};
+      *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(img + 16 * ((2 * cc + 1) ^ swz)) = u32x4{o[4], o[5], o[6], o[7]};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
     TMX_STAMP(ts3);
     TMX_SEG(0, ts0, ts1);
@@ -955,7 +994,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     frag qf[KS];
     wait_q();
     {
-      const char* qs = lds + NS * ENTRY + wave * QREG;
+      const char* qs = lds + NS * ENTRY + IMG + wave * QREG;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         qf[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(qs + (k_base ^ (64 * ks))));
@@ -1007,7 +1046,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     // tiles of the sparse rows have a half that no row of the wave attends to.  Same arithmetic as the
     // full step on half the keys; the second product uses the 16-key matrix instruction.
     auto process_half = [&](int tile_no, int kb, bool first) {
-      const unsigned eb = lds_base + (unsigned)gs_slot * ENTRY + (unsigned)kb * 16 * ROWB;
+      const unsigned eb = (FP8 ? lds_base + NS * ENTRY : lds_base + (unsigned)gs_slot * ENTRY) + (unsigned)kb * 16 * ROWB;
       const unsigned kl = eb + k_base, vl = eb + v_base;
       f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1094,7 +1133,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       unsigned kl[CNT], vl[CNT];
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
-        const unsigned eb = lds_base + (unsigned)slot_after(gs_slot, u) * ENTRY;
+        const unsigned eb = FP8 ? lds_base + NS * ENTRY : lds_base + (unsigned)slot_after(gs_slot, u) * ENTRY;
         kl[u] = eb + k_base;
         vl[u] = eb + v_base;
       }
@@ -1417,9 +1456,11 @@ static int persistent_grid(long long resident, const AttnParams& p, unsigned* gr
   return TMX_OK;
 }
 
-template <typename TR, int D, bool PAGED, bool HAS_BIAS>
+constexpr int kRingSlotsFp8 = 4;  // fp8 K/V: entries of half the size, one more of them
+
+template <typename TR, int D, bool PAGED, bool HAS_BIAS, bool FP8 = false>
 static int launch_attn(const AttnParams& p_in, hipStream_t s) {
-  auto kernel = attn_kernel<TR, D, kRingSlots, PAGED, HAS_BIAS>;
+  auto kernel = attn_kernel<TR, D, FP8 ? kRingSlotsFp8 : kRingSlots, PAGED, HAS_BIAS, FP8>;
   static unsigned resident_cache[kMaxDevices] = {0};  // per device: resident workgroups of this instantiation
   long long resident = 0;
   int cus = 0;
@@ -1427,7 +1468,7 @@ static int launch_attn(const AttnParams& p_in, hipStream_t s) {
   if (rc != TMX_OK) return rc;
   AttnParams p = p_in;
   unsigned grid = 0;
-  if (HAS_BIAS) p.band_on = 0;
+  if (HAS_BIAS || FP8) p.band_on = 0;
   if (p.band_on) {
     // Work-list workgroups: one per unit of the split q-blocks' pieces (they also take the few unsplit
     // q-blocks outside the canonical positions); band workgroups: runs of band_rl q-blocks per unit, about
@@ -1461,10 +1502,13 @@ static int launch_attn(const AttnParams& p_in, hipStream_t s) {
 }
 
 template <typename TR, int D>
-static int launch(const AttnParams& p, bool paged, bool has_bias, int64_t num_split, uint32_t flags, hipStream_t s) {
+static int launch(const AttnParams& p, bool paged, bool has_bias, bool fp8, int64_t num_split, uint32_t flags, hipStream_t s) {
   if (p.units_total > 0 && !(flags & TMX_ATTN_ONLY_COMBINE)) {
     int rc;
-    if (paged) rc = has_bias ? launch_attn<TR, D, true, true>(p, s) : launch_attn<TR, D, true, false>(p, s);
+    if (fp8) {
+      if constexpr (D == 128) rc = launch_attn<TR, 128, true, false, true>(p, s);
+      else rc = TMX_ERR_UNSUPPORTED;
+    } else if (paged) rc = has_bias ? launch_attn<TR, D, true, true>(p, s) : launch_attn<TR, D, true, false>(p, s);
     else rc = has_bias ? launch_attn<TR, D, false, true>(p, s) : launch_attn<TR, D, false, false>(p, s);
     if (rc != TMX_OK) return rc;
   }
@@ -1550,6 +1594,18 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
                         "tmx_attention: page_size %d not supported (powers of two >= 16 are)", a->page_size);
   else TMX_CHECK_ARG(a->cu_seqlens_k != nullptr, "tmx_attention: contiguous K/V needs cu_seqlens_k");
   const bool has_bias = a->bias != nullptr;
+  const bool fp8 = a->kv_dtype == TMX_FP8_E4M3;
+  TMX_CHECK_SUPPORTED(a->kv_dtype == 0 || a->kv_dtype == a->io_dtype || fp8,
+                      "tmx_attention: kv_dtype %d not supported (0 / the q dtype, or TMX_FP8_E4M3)", a->kv_dtype);
+  if (fp8) {
+    TMX_CHECK_SUPPORTED(paged && !has_bias && a->head_dim == 128,
+                        "tmx_attention: an fp8 K/V cache needs the paged layout, head_dim 128 and no bias "
+                        "(other cases: tmx_gather_dequant_kv_fp8 ahead of the call)");
+    TMX_CHECK_ARG(a->k_scale > 0.f && a->v_scale > 0.f && a->k_scale < 3.0e38f && a->v_scale < 3.0e38f,
+                  "tmx_attention: k_scale / v_scale must be positive and finite");
+    TMX_CHECK_ARG(a->kv_stride_t % 16 == 0 && a->kv_stride_h % 16 == 0 && a->kv_stride_page % 16 == 0,
+                  "tmx_attention: fp8 cache strides must be multiples of 16 bytes");
+  }
   if (has_bias)
     TMX_CHECK_ARG((a->bias_dtype == TMX_F32 || a->bias_dtype == TMX_BF16 || a->bias_dtype == TMX_F16) &&
                       a->bias_rows > 0 && a->bias_cols > 0 && a->bias_stride >= a->bias_cols,
@@ -1620,6 +1676,8 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.bias_dtype = a->bias_dtype;
   p.out_dtype = a->out_dtype;
   p.scale_log2 = a->scale * kLog2e;
+  p.k_scale = fp8 ? a->k_scale : 1.f;
+  p.v_scale = fp8 ? a->v_scale : 1.f;
 
   p.Y = a->num_kv_heads * (G / p.Gw);
   p.num_items = (int)a->num_items;
@@ -1675,15 +1733,18 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
     d.total_q = a->total_q;
     d.out_dtype = a->out_dtype;
     d.scale_log2 = p.scale_log2;
+    d.kv_fp8 = fp8 ? 1 : 0;
+    d.k_scale = p.k_scale;
+    d.v_scale = p.v_scale;
     const int rc = launch_dense_causal(d, a->io_dtype == TMX_BF16, paged, s);
     if (rc != TMX_OK) return rc;
   }
   if (a->io_dtype == TMX_BF16) {
-    if (a->head_dim == 128) return launch<Bf16Traits, 128>(p, paged, has_bias, a->num_split_qblocks, a->flags, s);
-    return launch<Bf16Traits, 64>(p, paged, has_bias, a->num_split_qblocks, a->flags, s);
+    if (a->head_dim == 128) return launch<Bf16Traits, 128>(p, paged, has_bias, fp8, a->num_split_qblocks, a->flags, s);
+    return launch<Bf16Traits, 64>(p, paged, has_bias, fp8, a->num_split_qblocks, a->flags, s);
   }
-  if (a->head_dim == 128) return launch<F16Traits, 128>(p, paged, has_bias, a->num_split_qblocks, a->flags, s);
-  return launch<F16Traits, 64>(p, paged, has_bias, a->num_split_qblocks, a->flags, s);
+  if (a->head_dim == 128) return launch<F16Traits, 128>(p, paged, has_bias, fp8, a->num_split_qblocks, a->flags, s);
+  return launch<F16Traits, 64>(p, paged, has_bias, fp8, a->num_split_qblocks, a->flags, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

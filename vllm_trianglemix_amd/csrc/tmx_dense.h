@@ -30,6 +30,8 @@ struct DenseParams {
   int batch, total_q;
   int out_dtype;
   float scale_log2;
+  int kv_fp8;               // K/V are an fp8 (e4m3fn) paged cache: strides in bytes, value = fp8 x scale
+  float k_scale, v_scale;
 };
 
 int launch_dense_causal(const DenseParams& p, bool bf16, bool paged, hipStream_t s);

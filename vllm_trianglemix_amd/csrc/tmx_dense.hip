@@ -77,8 +77,13 @@ __device__ __forceinline__ s16x4_t lds_tr16(unsigned addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)addr);
 }
 
-template <bool BF16, bool PAGED>
+// KV8: K and V are an fp8 (e4m3fn) paged cache; a thread then carries 16 bytes (16 values) of a row per tensor
+// and the staging step descales them: value = fp8 x scale, rounded once to the 16-bit type of q (what the
+// reference's kernels do with k_descale / v_descale, vllm/v1/attention/backends/rocm_attn.py:421-422).
+template <bool BF16, bool PAGED, bool KV8>
 __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams p) {
+  static_assert(!KV8 || PAGED, "an fp8 cache is paged");
+  constexpr int KVB = KV8 ? 1 : 2;  // bytes per K/V element in memory
   __shared__ __attribute__((aligned(1024))) char lds[4 * kDTile];  // [buffer][K | V]
   __shared__ int blk_ptr[kDenseMaxBatch + 1];                       // first 64-row block of every request
 
@@ -130,9 +135,9 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
   const unsigned st_k1 = srow * kDRowB + 16 * ((2 * sc2 + 1) ^ (srow & 15));
   const unsigned st_v0 = kDTile + srow * kDRowB + 16 * ((2 * sc2) ^ ((srow & 3) << 2));
   const unsigned st_v1 = kDTile + srow * kDRowB + 16 * ((2 * sc2 + 1) ^ ((srow & 3) << 2));
-  const int kv_row_bytes = 2 * p.kv_stride_t;
-  const char* const k_head = reinterpret_cast<const char*>(p.k) + 2ll * kvh * p.kv_stride_h + 32 * sc2;
-  const char* const v_head = reinterpret_cast<const char*>(p.v) + 2ll * kvh * p.kv_stride_h + 32 * sc2;
+  const int kv_row_bytes = KVB * p.kv_stride_t;
+  const char* const k_head = reinterpret_cast<const char*>(p.k) + (long long)KVB * kvh * p.kv_stride_h + 16 * KVB * sc2;
+  const char* const v_head = reinterpret_cast<const char*>(p.v) + (long long)KVB * kvh * p.kv_stride_h + 16 * KVB * sc2;
 
   const int rounds = (num_blocks + lanes_per_unit - 1) / lanes_per_unit;
 #pragma unroll 1
@@ -183,16 +188,44 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
       long long off;
       if constexpr (PAGED) {
         const long long pg = dsload(bt + (key_w >> p.page_shift));
-        off = 2ll * pg * p.kv_stride_page + (long long)(key & (p.page_size - 1)) * kv_row_bytes;
+        off = (long long)KVB * pg * p.kv_stride_page + (long long)(key & (p.page_size - 1)) * kv_row_bytes;
       } else {
         off = (krow0 + key) * kv_row_bytes;
       }
       kreg[0] = *reinterpret_cast<const uint4*>(k_head + off);
-      kreg[1] = *reinterpret_cast<const uint4*>(k_head + off + 16);
       vreg[0] = *reinterpret_cast<const uint4*>(v_head + off);
-      vreg[1] = *reinterpret_cast<const uint4*>(v_head + off + 16);
+      if constexpr (!KV8) {
+        kreg[1] = *reinterpret_cast<const uint4*>(k_head + off + 16);
+        vreg[1] = *reinterpret_cast<const uint4*>(v_head + off + 16);
+      }
     };
-    auto stage = [&](unsigned buf, const uint4 (&kreg)[2], uint4 (&vreg)[2]) {
+    auto stage = [&](unsigned buf, uint4 (&kreg)[2], uint4 (&vreg)[2]) {
+      if constexpr (KV8) {
+        // 16 fp8 values per tensor -> two 16-byte chunks of 16-bit values
+        const uint32_t kw[4] = {kreg[0].x, kreg[0].y, kreg[0].z, kreg[0].w};
+        const uint32_t vw[4] = {vreg[0].x, vreg[0].y, vreg[0].z, vreg[0].w};
+        uint32_t ko[8], vo[8];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const auto klo = __builtin_amdgcn_cvt_pk_f32_fp8((int)kw[x], false), khi = __builtin_amdgcn_cvt_pk_f32_fp8((int)kw[x], true);
+          const auto vlo = __builtin_amdgcn_cvt_pk_f32_fp8((int)vw[x], false), vhi = __builtin_amdgcn_cvt_pk_f32_fp8((int)vw[x], true);
+          if constexpr (BF16) {
+            ko[2 * x] = pack_bf16(klo[0] * p.k_scale, klo[1] * p.k_scale);
+            ko[2 * x + 1] = pack_bf16(khi[0] * p.k_scale, khi[1] * p.k_scale);
+            vo[2 * x] = pack_bf16(vlo[0] * p.v_scale, vlo[1] * p.v_scale);   // (converted on to fp16 below)
+            vo[2 * x + 1] = pack_bf16(vhi[0] * p.v_scale, vhi[1] * p.v_scale);
+          } else {
+            ko[2 * x] = pack_f16(klo[0] * p.k_scale, klo[1] * p.k_scale);
+            ko[2 * x + 1] = pack_f16(khi[0] * p.k_scale, khi[1] * p.k_scale);
+            vo[2 * x] = pack_f16(vlo[0] * p.v_scale, vlo[1] * p.v_scale);
+            vo[2 * x + 1] = pack_f16(vhi[0] * p.v_scale, vhi[1] * p.v_scale);
+          }
+        }
+        kreg[0] = make_uint4(ko[0], ko[1], ko[2], ko[3]);
+        kreg[1] = make_uint4(ko[4], ko[5], ko[6], ko[7]);
+        vreg[0] = make_uint4(vo[0], vo[1], vo[2], vo[3]);
+        vreg[1] = make_uint4(vo[4], vo[5], vo[6], vo[7]);
+      }
       if constexpr (BF16) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
@@ -379,12 +412,19 @@ int launch_dense_causal(const DenseParams& p, bool bf16, bool paged, hipStream_t
   const long long units = ((long long)p.total_q / kDM + p.batch) * p.Y;  // upper bound of the blocks x chunks
   if (grid > units) grid = units - units % p.Y;
   if (grid < p.Y) grid = p.Y;
-  if (bf16) {
-    if (paged) dense_causal_kernel<true, true><<<(unsigned)grid, 512, 0, s>>>(p);
-    else dense_causal_kernel<true, false><<<(unsigned)grid, 512, 0, s>>>(p);
+  if (p.kv_fp8) {
+    if (!paged) {
+      set_error("dense causal kernel: an fp8 K/V cache is paged");
+      return TMX_ERR_INVALID_ARG;
+    }
+    if (bf16) dense_causal_kernel<true, true, true><<<(unsigned)grid, 512, 0, s>>>(p);
+    else dense_causal_kernel<false, true, true><<<(unsigned)grid, 512, 0, s>>>(p);
+  } else if (bf16) {
+    if (paged) dense_causal_kernel<true, true, false><<<(unsigned)grid, 512, 0, s>>>(p);
+    else dense_causal_kernel<true, false, false><<<(unsigned)grid, 512, 0, s>>>(p);
   } else {
-    if (paged) dense_causal_kernel<false, true><<<(unsigned)grid, 512, 0, s>>>(p);
-    else dense_causal_kernel<false, false><<<(unsigned)grid, 512, 0, s>>>(p);
+    if (paged) dense_causal_kernel<false, true, false><<<(unsigned)grid, 512, 0, s>>>(p);
+    else dense_causal_kernel<false, false, false><<<(unsigned)grid, 512, 0, s>>>(p);
   }
   TMX_CHECK_HIP(hipGetLastError());
   return TMX_OK;

@@ -19,6 +19,7 @@ from ._lib import (AttentionArgs, Index, IndexSizes, TMX_BF16, TMX_F16, TMX_F32,
 DEFAULT_CHUNK_TILES = 64  # key tiles per work item before a q-block is split (64 x 32 = 2048 keys)
 
 _DTYPE = {torch.float32: TMX_F32, torch.bfloat16: TMX_BF16, torch.float16: TMX_F16}
+FP8_DTYPE = torch.float8_e4m3fn  # the K/V cache format vllm/platforms/rocm.py:402-406 selects on gfx950
 MODES = {"none": TMX_MODE_NONE, "causal": TMX_MODE_CAUSAL, "triangle": TMX_MODE_TRIANGLE}
 MASK_KINDS = {"streaming": 0, "last": 1, "middle": 2, "triangle": 3, "dense": 4}
 
@@ -256,8 +257,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
               cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, scale: float,
               cu_seqlens_k: Optional[torch.Tensor] = None, block_table: Optional[torch.Tensor] = None,
               bias: Optional[torch.Tensor] = None, workspace: Optional[Sequence[torch.Tensor]] = None,
-              flags: int = 0, static_workspace: bool = False) -> torch.Tensor:
+              flags: int = 0, static_workspace: bool = False, k_scale: float = 1.0, v_scale: float = 1.0
+              ) -> torch.Tensor:
     """Masked attention over the tiles ``index`` lists.
+
+    An fp8 (e4m3fn) paged cache (``k``/``v`` of dtype uint8 or float8_e4m3fn, as ``reshape_and_cache_fp8`` writes
+    it) is read in place: the kernel descales inside its tile loop with ``k_scale`` / ``v_scale`` (head size 128).
 
     ``static_workspace``: call ``tmx_attention_static_ws`` -- the partial results of split q-blocks go
     to the library's fixed device array instead of ``workspace`` (nothing is allocated; steps that need
@@ -273,8 +278,14 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
         _require_gpu(t, name)
     if q.dim() != 3 or out.dim() != 3 or q.shape != out.shape:
         raise RuntimeError("q and out must both be [T, H, D]")
-    if q.dtype not in (torch.bfloat16, torch.float16) or k.dtype != q.dtype or v.dtype != q.dtype:
-        raise RuntimeError("q, k, v must share a dtype of bfloat16 or float16")
+    fp8 = k.dtype in (torch.uint8, FP8_DTYPE)
+    if fp8:
+        if block_table is None or bias is not None or q.shape[-1] != 128:
+            raise RuntimeError("an fp8 K/V cache is read in place only in the paged layout, with head size 128 and "
+                               "no bias (otherwise: gather_dequant_kv_fp8 first)")
+        k, v = _as_bytes(k), _as_bytes(v)
+    if q.dtype not in (torch.bfloat16, torch.float16) or (not fp8 and (k.dtype != q.dtype or v.dtype != q.dtype)):
+        raise RuntimeError("q, k, v must share a dtype of bfloat16 or float16 (or K/V be an fp8 cache)")
     if q.stride(2) != 1 or out.stride(2) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
         raise RuntimeError("the head dimension must be contiguous")
     if k.shape != v.shape or k.stride() != v.stride():
@@ -309,6 +320,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
         a.cu_seqlens_k = cu_seqlens_k.data_ptr()
     if k.shape[-1] != D:
         raise RuntimeError("k/v head size differs from q")
+    a.kv_dtype, a.k_scale, a.v_scale = (_lib.TMX_FP8_E4M3, float(k_scale), float(v_scale)) if fp8 else (0, 1.0, 1.0)
     a.cu_seqlens_q, a.seq_lens = cu_seqlens_q.data_ptr(), seq_lens.data_ptr()
     if bias is not None:
         _require_gpu(bias, "bias")
@@ -374,8 +386,6 @@ def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.T
 
 
 # --------------------------------------------------------------------------- fp8 K/V cache
-FP8_DTYPE = torch.float8_e4m3fn  # the format vllm/platforms/rocm.py:402-406 selects on gfx950
-
 
 def _as_bytes(cache: torch.Tensor) -> torch.Tensor:
     if cache.dtype not in (torch.uint8, FP8_DTYPE):
