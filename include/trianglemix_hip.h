@@ -229,6 +229,20 @@ typedef struct tmx_attention_args_t {
    * no bias. */
   int32_t kv_dtype;
   float k_scale, v_scale;
+  /* Optional second source of keys / values (paged 16-bit cache only): the step's own key / value rows, the
+   * tensors tmx_reshape_and_cache takes ([total_q, num_kv_heads, head_dim], row t belongs to query row t; strides
+   * in elements).  Request b's keys from position seq_lens[b] - q_len on are then read from these rows and only
+   * the earlier ones from the cache, so the call does not depend on the cache write of the same step: the
+   * reference writes first and reads the cache back (vllm/v1/attention/backends/rocm_attn.py:345-354, 398-426);
+   * here the write may run beside the attention on another stream.  Same values either way. */
+  const void* k_new;
+  const void* v_new;
+  int64_t new_stride_t, new_stride_h;
+  /* Optional, with k_new / v_new: the cache write of the step, fused into this call.  Row t of k_new / v_new is
+   * also stored to flat slot cache_slots[t] of the paged cache k / v (slot = page * page_size + offset, negative:
+   * skipped): the contract of tmx_reshape_and_cache, which then need not be called.  The cache must be writable;
+   * the stores are complete when the call's work on the stream is. */
+  const int64_t* cache_slots; /* (device) [total_q] or NULL */
 
   const int32_t* cu_seqlens_q; /* (device) [batch + 1] */
   const int32_t* seq_lens;     /* (device) [batch] */

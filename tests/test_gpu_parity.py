@@ -773,8 +773,8 @@ def test_backend_whole_prompt_step_reads_rows_beside_cache_write(monkeypatch):
     qd, kd, vd = qkv.split([H * D, Hkv * D, Hkv * D], dim=-1)
     qd, kd, vd = qd.view(T, H, D), kd.view(T, Hkv, D), vd.view(T, Hkv, D)
     results = []
-    for overlap in (False, True):
-        monkeypatch.setattr(be, "_CACHE_WRITE_STREAM", overlap)
+    for write_mode in ("serial", "stream", "fused"):
+        monkeypatch.setattr(be, "_CACHE_WRITE_MODE", write_mode)
         common = types.SimpleNamespace(
             num_actual_tokens=T, max_query_len=max(q_lens), max_seq_len=max(seq_lens),
             query_start_loc=torch.from_numpy(cu).to(DEV), query_start_loc_cpu=torch.from_numpy(cu),
@@ -796,7 +796,8 @@ def test_backend_whole_prompt_step_reads_rows_beside_cache_write(monkeypatch):
         torch.cuda.current_stream().synchronize()
         assert torch.equal(flat[0], kd) and torch.equal(flat[1], vd)
         results.append((out.clone(), kv_cache.clone()))
-    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+    for other in results[1:]:
+        assert torch.equal(results[0][0], other[0]) and torch.equal(results[0][1], other[1])
     got = results[0][0].float().cpu().numpy().reshape(T, H, D)
     ref = np.zeros((T, H, D))
     for b, s in enumerate(seq_lens):
@@ -1236,3 +1237,88 @@ def test_fp8_cache_read_in_place(dtype, page):
         ops.attention(q64, torch.zeros((2, page, 2, 64), dtype=torch.uint8, device=DEV),
                       torch.zeros((2, page, 2, 64), dtype=torch.uint8, device=DEV), torch.empty_like(q64), idx, cu, sld,
                       1.0, block_table=btd)
+
+
+def test_two_sources_equal_cache_only_and_backend_overlaps_every_step(monkeypatch):
+    """k_new / v_new: a request's keys from position seq_len - q_len on are read from the step's own rows, the
+    earlier ones from the paged cache.  Bit-identical to reading everything from a fully written cache, for a
+    chunk continuation with a 32-aligned context (band path), an unaligned one (tiles that hold both kinds), decode
+    rows and a whole prompt, with the triangle pattern and causally (dense kernel); the rows of the step need
+    NOT be in the cache yet (the cache holds garbage there).  Then through the backend: with the write on the
+    second stream the cache ends up bit-identical and the output too."""
+    import types
+    from vllm_trianglemix_amd import TriangleMixConfig
+    from vllm_trianglemix_amd import backend as be
+    ops = _ops()
+    H, Hkv, D, page = 8, 2, 128, 16
+    q_lens, seq_lens = [1024, 600, 1, 1, 300, 40], [3072, 2999, 2500, 17, 300, 2100]
+    q, ks, vs = _rand_case(5150, q_lens, seq_lens, H, Hkv, D)
+    scale = D ** -0.5
+    B = len(seq_lens)
+    cu = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    T = int(cu[-1])
+    nblk = sum((s + page - 1) // page for s in seq_lens) + 2
+    perm = np.random.default_rng(12).permutation(nblk).astype(np.int32)
+    bt = np.zeros((B, max((s + page - 1) // page for s in seq_lens)), np.int32)
+    full = torch.zeros((2, nblk, page, Hkv, D), dtype=torch.bfloat16, device=DEV)
+    part = torch.full((2, nblk, page, Hkv, D), 7.0, dtype=torch.bfloat16, device=DEV)  # garbage where the step's rows go
+    # the step's rows as strided slices of one fused projection output
+    qkv = torch.zeros((T, (H + 2 * Hkv) * D), dtype=torch.bfloat16, device=DEV)
+    slots = np.zeros((T,), np.int64)
+    nxt = 0
+    for b, (ql, s) in enumerate(zip(q_lens, seq_lens)):
+        for pb in range((s + page - 1) // page):
+            bt[b, pb] = perm[nxt]
+            nxt += 1
+        pos = np.arange(s)
+        sl_all = torch.from_numpy(bt[b, pos // page].astype(np.int64) * page + pos % page).to(DEV)
+        kd, vd = _to_dev(ks[b], torch.bfloat16), _to_dev(vs[b], torch.bfloat16)
+        ops.reshape_and_cache(kd, vd, full[0], full[1], sl_all)
+        ctx = s - ql
+        if ctx:
+            ops.reshape_and_cache(kd[:ctx], vd[:ctx], part[0], part[1], sl_all[:ctx])
+        slots[cu[b]:cu[b + 1]] = sl_all[ctx:].cpu().numpy()
+        qkv[cu[b]:cu[b + 1], H * D:(H + Hkv) * D] = kd[ctx:].reshape(ql, Hkv * D)
+        qkv[cu[b]:cu[b + 1], (H + Hkv) * D:] = vd[ctx:].reshape(ql, Hkv * D)
+    qkv[:, :H * D] = _to_dev(q, torch.bfloat16).view(T, H * D)
+    qd, kn, vn = qkv.split([H * D, Hkv * D, Hkv * D], dim=-1)
+    qd, kn, vn = qd.view(T, H, D), kn.view(T, Hkv, D), vn.view(T, Hkv, D)
+    btd = torch.from_numpy(bt).to(DEV)
+    bm = ops.attention_block_m(H, Hkv)
+    for mode, pat, gate in (("triangle", (4, 32, 64), 2048), ("causal", (0, 0, 0), 0)):
+        idx, cud, sld = _build(ops, q_lens, seq_lens, *pat, bm, 32, ops.MODES[mode], 16, gate, block_table=btd, page_size=page)
+        want = torch.empty((T, H, D), dtype=torch.float32, device=DEV)
+        got = torch.empty_like(want)
+        ops.attention(qd, full[0], full[1], want, idx, cud, sld, scale, block_table=btd)
+        ops.attention(qd, part[0], part[1], got, idx, cud, sld, scale, block_table=btd, k_new=kn, v_new=vn)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (mode, (got - want).abs().max().item())
+        ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu, seq_lens, scale, mode, *pat, tri_min_len=gate)
+        assert np.abs(got.cpu().numpy() - ref).max() <= ATOL_F32_OUT
+    # through the backend, write beside the attention against write first
+    results = []
+    for write_mode in ("serial", "stream", "fused"):
+        monkeypatch.setattr(be, "_CACHE_WRITE_MODE", write_mode)
+        common = types.SimpleNamespace(
+            num_actual_tokens=T, max_query_len=max(q_lens), max_seq_len=max(seq_lens),
+            query_start_loc=torch.from_numpy(cu).to(DEV), query_start_loc_cpu=torch.from_numpy(cu),
+            seq_lens=torch.tensor(seq_lens, dtype=torch.int32, device=DEV), seq_lens_cpu=torch.tensor(seq_lens, dtype=torch.int32),
+            block_table_tensor=btd, slot_mapping=torch.from_numpy(slots).to(DEV))
+        md = be.TriangleMixAttentionBackend.get_builder_cls()(types.SimpleNamespace(block_size=page), ["l0"], None,
+                                                              torch.device(DEV)).build(0, common)
+        assert not md.whole_prompts
+        impl = be.TriangleMixAttentionBackend.get_impl_cls()(H, D, scale, Hkv, None, None, "auto", None, "decoder", None,
+                                                             trianglemix_config=TriangleMixConfig(num_triangle_layers=1),
+                                                             layer_idx=0)
+        cache = part.clone()
+        out = torch.zeros((T, H * D), dtype=torch.bfloat16, device=DEV)
+        impl.forward(None, qd, kn, vn, cache, md, output=out)
+        torch.cuda.current_stream().synchronize()
+        results.append((out.clone(), cache.clone()))
+    for other in results[1:]:
+        assert torch.equal(results[0][0], other[0]) and torch.equal(results[0][1], other[1])
+    used = torch.zeros(nblk * page, dtype=torch.bool, device=DEV)
+    for b, s in enumerate(seq_lens):
+        pos = np.arange(s)
+        used[torch.from_numpy(bt[b, pos // page].astype(np.int64) * page + pos % page).to(DEV)] = True
+    assert torch.equal(results[2][1].view(2, nblk * page, Hkv, D)[:, used], full.view(2, nblk * page, Hkv, D)[:, used])

@@ -61,6 +61,8 @@ class AttentionArgs(Structure):
         ("kv_stride_page", c_int64), ("kv_stride_t", c_int64), ("kv_stride_h", c_int64),
         ("block_table", c_void_p), ("block_table_stride", c_int64), ("page_size", c_int32),
         ("cu_seqlens_k", c_void_p), ("kv_dtype", c_int32), ("k_scale", c_float), ("v_scale", c_float),
+        ("k_new", c_void_p), ("v_new", c_void_p), ("new_stride_t", c_int64), ("new_stride_h", c_int64),
+        ("cache_slots", c_void_p),
         ("cu_seqlens_q", c_void_p), ("seq_lens", c_void_p),
         ("bias", c_void_p), ("bias_dtype", c_int32), ("bias_stride", c_int64),
         ("bias_rows", c_int32), ("bias_cols", c_int32),

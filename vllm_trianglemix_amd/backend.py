@@ -150,9 +150,14 @@ class TriangleMixAttentionMetadata:
         return ws
 
 
-# One extra stream per device for the cache write of whole-prompt steps.  TRIANGLEMIX_CACHE_WRITE_STREAM=0
-# keeps everything on the caller's stream.
-_CACHE_WRITE_STREAM = os.environ.get("TRIANGLEMIX_CACHE_WRITE_STREAM", "1") != "0"
+# How the step's K/V rows reach the 16-bit paged cache (TRIANGLEMIX_CACHE_WRITE):
+#   "fused"  (default) the attention launch stores them itself (cache_slots) and reads the step's keys from the
+#            rows, not from the cache: one launch per layer, no second stream;
+#   "stream" the write kernel runs beside the attention on a second stream (joined before forward returns);
+#   "serial" write kernel, then attention over the cache, on the caller's stream (what the reference does,
+#            rocm_attn.py:345-354).
+_CACHE_WRITE_MODE = os.environ.get("TRIANGLEMIX_CACHE_WRITE", "fused")
+_CACHE_WRITE_STREAM = os.environ.get("TRIANGLEMIX_CACHE_WRITE_STREAM", "1") != "0"  # "stream" mode's switch
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -342,23 +347,35 @@ class TriangleMixAttentionImpl(_ImplBase):
         tri_min_len = self.tri_min_len if self.use_triangle else 0
         idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len)
         ws = m.workspace(idx, self.num_heads, self.head_size, q.device)
-        if writes_cache and m.whole_prompts and _CACHE_WRITE_STREAM and n_tok > 0:
-            # Whole prompts: every key of the step is in `key` / `value` already, so the attention reads those
-            # rows (request b's key j is row query_start_loc[b] + j) and does not wait for the cache write,
-            # which runs beside it on a second stream and is joined before anything else follows on this one
-            # (32k-token prompt, Qwen3-8B heads: 227 us against 248 us one after the other).
+        k_rows = v_rows = None
+        if writes_cache and n_tok > 0:
+            k_rows = key[:n_tok].view(n_tok, self.num_kv_heads, self.head_size)
+            v_rows = value[:n_tok].view(n_tok, self.num_kv_heads, self.head_size)
+        if k_rows is not None and _CACHE_WRITE_MODE == "fused":
+            # One launch: every workgroup first stores its share of the step's rows to their cache slots, and the
+            # attention reads the step's keys from the rows themselves (earlier context from the paged cache).
+            ops.attention(q, key_cache, value_cache, out, idx, m.query_start_loc, m.seq_lens, self.scale,
+                          block_table=m.block_table, workspace=ws, flags=_step_flags(m), k_new=k_rows, v_new=v_rows,
+                          cache_slots=m.slot_mapping[:n_tok])
+            return output
+        if k_rows is not None and _CACHE_WRITE_MODE == "stream" and _CACHE_WRITE_STREAM:
+            # The write kernel beside the attention on a second stream, joined before anything else follows on
+            # this one.  Whole prompts attend to the rows directly (request b's key j is row query_start_loc[b] + j);
+            # steps with context read the earlier keys from the paged cache and the step's from the rows.
             main = torch.cuda.current_stream(q.device)
             side = _side_stream(q.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 ops.reshape_and_cache(key[:n_tok], value[:n_tok], key_cache, value_cache, m.slot_mapping[:n_tok])
-            k_rows = key[:n_tok].view(n_tok, self.num_kv_heads, self.head_size)
-            v_rows = value[:n_tok].view(n_tok, self.num_kv_heads, self.head_size)
-            ops.attention(q, k_rows, v_rows, out, idx, m.query_start_loc, m.seq_lens, self.scale,
-                          cu_seqlens_k=m.query_start_loc, workspace=ws, flags=_step_flags(m))
+            if m.whole_prompts:
+                ops.attention(q, k_rows, v_rows, out, idx, m.query_start_loc, m.seq_lens, self.scale,
+                              cu_seqlens_k=m.query_start_loc, workspace=ws, flags=_step_flags(m))
+            else:
+                ops.attention(q, key_cache, value_cache, out, idx, m.query_start_loc, m.seq_lens, self.scale,
+                              block_table=m.block_table, workspace=ws, flags=_step_flags(m), k_new=k_rows, v_new=v_rows)
             main.wait_stream(side)
             return output
-        if writes_cache:
+        if k_rows is not None:
             ops.reshape_and_cache(key[:n_tok], value[:n_tok], key_cache, value_cache, m.slot_mapping[:n_tok])
         ops.attention(q, key_cache, value_cache, out, idx, m.query_start_loc, m.seq_lens, self.scale,
                       block_table=m.block_table, workspace=ws, flags=_step_flags(m))

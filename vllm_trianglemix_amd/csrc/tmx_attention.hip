@@ -129,6 +129,11 @@ struct AttnParams {
   unsigned long long* stamps;  // diagnostic builds only
   const int32_t* tile_pages;   // [nnz][2] physical pages of each listed tile's halves, or NULL
   const int32_t* full_lens;    // [batch] length of each sequence once its prompt is complete, or NULL
+  const void* k_new;           // the step's own K / V rows ([total_q, Hkv, D], row t belongs to query row t), or NULL:
+  const void* v_new;           // keys from position seq_len - q_len on are read there instead of the paged cache
+  int new_stride_t, new_stride_h;
+  const long long* cache_slots;  // [total_q] flat cache slot of every row of k_new / v_new (negative: none), or NULL
+  int total_q;
   int q_stride_t, q_stride_h, out_stride_t, out_stride_h;  // elements; checked to fit 31 bits
   int kv_stride_page, kv_stride_t, kv_stride_h, block_table_stride;
   int64_t bias_stride;
@@ -276,6 +281,36 @@ __device__ __forceinline__ void wait_vmcnt_levels(int n) {
 #define TMX_SEG(idx, t0, t1) do { } while (0)
 #endif
 
+// The cache write of the step, fused into the attention launch (the reference's reshape_and_cache_flash,
+// csrc/cache_kernels.cu:282-355, called ahead of its attention kernel at
+// vllm/v1/attention/backends/rocm_attn.py:345-354): before its own work every workgroup copies its share of the
+// step's key / value rows to their cache slots.  Nothing in this launch reads those slots -- the keys of the
+// step come from k_new / v_new -- so the copy needs no ordering against the attention; the next launch on the
+// stream sees the finished cache.
+template <int D>
+__device__ __forceinline__ void fused_cache_write(const AttnParams& p) {
+  constexpr int CPR = D / 8;  // 16-byte chunks per row of one head
+  const int units = p.total_q * p.Hkv * CPR;  // (row, head, chunk), below 2^31 (checked on the host)
+  const int stride = (int)gridDim.x * (int)blockDim.x;
+  const uint16_t* kn = reinterpret_cast<const uint16_t*>(p.k_new);
+  const uint16_t* vn = reinterpret_cast<const uint16_t*>(p.v_new);
+  uint16_t* kc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.k));
+  uint16_t* vc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.v));
+  for (int u = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x; u < units; u += stride) {
+    const int c = u % CPR, th = u / CPR;
+    const int h = th % p.Hkv, t = th / p.Hkv;
+    const long long slot = p.cache_slots[t];
+    if (slot < 0) continue;
+    const long long src = (long long)t * p.new_stride_t + (long long)h * p.new_stride_h + 8 * c;
+    const long long dst = (slot >> p.page_shift) * p.kv_stride_page + (slot & (p.page_size - 1)) * (long long)p.kv_stride_t +
+                          (long long)h * p.kv_stride_h + 8 * c;
+    const uint4 kx = *reinterpret_cast<const uint4*>(kn + src);
+    const uint4 vx = *reinterpret_cast<const uint4*>(vn + src);
+    *reinterpret_cast<uint4*>(kc + dst) = kx;
+    *reinterpret_cast<uint4*>(vc + dst) = vx;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Band path.  In a long triangle request almost every q-block is in "canonical position": 32 full rows
 // starting at a multiple of 32, none of them among the trailing dense rows, its window clear of the sink
@@ -332,6 +367,8 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
     const int row = r8 + x * RPP + lane / CPR;
     kv_voff[x] = row * kv_row_bytes + 16 * ((lane % CPR) ^ (t_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row)));
   }
+  const int new_row_bytes = 2 * p.new_stride_t;
+  const char* const new_src = reinterpret_cast<const char*>(t_v ? p.v_new : p.k_new) + 2ll * kvh * p.new_stride_h;
   const unsigned dma_off = (unsigned)(t_v * 16 * ROWB + r8 * ROWB);
   const unsigned sink_base = lds_base + NSLOT * HALFB;
   auto slot_base = [&](int half_no) { return lds_base + (unsigned)(half_no % NSLOT) * HALFB; };
@@ -392,13 +429,26 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
     }
     const long long krow0 = PAGED ? 0 : (long long)sload(p.cu_k + b);
     const int32_t* const bt = PAGED ? p.block_table + (long long)b * p.block_table_stride : nullptr;
-    // byte offset of the 16-key half that starts at key0 (one page, or part of one, of a paged cache)
+    // Byte offset of the 16-key half that starts at key0 (one page, or part of one, of a paged cache).  Two
+    // sources: halves from position ctx on are rows of the step's own tensors, flagged by bit 0 of the offset
+    // (offsets are multiples of 16; a band request's context is a multiple of 32, so no half holds both kinds).
     auto half_offset = [&](int key0) -> long long {
-      if constexpr (PAGED)
+      if constexpr (PAGED) {
+        if (p.k_new != nullptr && key0 >= ctx) return ((long long)(q_start - ctx + key0) * new_row_bytes) | 1;
         return 2ll * sload(bt + (key0 >> p.page_shift)) * p.kv_stride_page + (long long)(key0 & (p.page_size - 1)) * kv_row_bytes;
-      else return (krow0 + key0) * kv_row_bytes;
+      } else {
+        return (krow0 + key0) * kv_row_bytes;
+      }
     };
     auto issue_at = [&](long long off, unsigned half_base) {
+      if (PAGED && (off & 1)) {
+        const int lrow = opaque(lane) / CPR;
+#pragma unroll
+        for (int x = 0; x < PWB; ++x)
+          glds16_s(new_src + (off - 1), kv_voff[x] + (r8 + x * RPP + lrow) * (new_row_bytes - kv_row_bytes),
+                   half_base + dma_off + x * 1024);
+        return;
+      }
 #pragma unroll
       for (int x = 0; x < PWB; ++x) glds16_s(kv_src + off, kv_voff[x], half_base + dma_off + x * 1024);
     };
@@ -651,6 +701,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   // of sparse q-blocks in canonical position (band_body).  One launch, so that the arithmetic-bound pieces of
   // the dense rows and the memory-bound sparse q-blocks share the CUs.
   const int bid = (int)blockIdx.x, ngrid = p.n_generic;
+  if constexpr (PAGED && !FP8) {
+    if (p.cache_slots != nullptr) fused_cache_write<D>(p);
+  }
   if constexpr (!HAS_BIAS && !FP8) {
     if (bid >= ngrid) {
 #ifdef TMX_TUNING
@@ -690,6 +743,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   const bool iss_second = pit0 * KRPP >= 16;  // keys 16..31 of the tile
   const char* const kv_iss =
       reinterpret_cast<const char*>(iss_v ? p.v : p.k) + (long long)KVB * kvh * p.kv_stride_h;
+  // (two sources: the same tensor of the step's own rows)
+  const int new_row_bytes = 2 * p.new_stride_t;
+  const char* const kn_iss = reinterpret_cast<const char*>(iss_v ? p.v_new : p.k_new) + 2ll * kvh * p.new_stride_h;
   const char* const q_own = reinterpret_cast<const char*>(p.q) + 2ll * head * p.q_stride_h;
   const unsigned q_lds = lds_base + NS * ENTRY + IMG + wave * QREG;
   int kv_voff[PW], q_voff[QP];
@@ -776,6 +832,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   int d_tile = 0;
   long long d_off0 = 0, d_off1 = 0;  // byte offsets of the pages holding the tile's keys 0..15 / 16..31
   long long i_krow0 = 0;             // contiguous K/V: first row of the cursor's request
+  int i_ctx = 0x7fffffff;            // two sources: keys from this position on come from the step's own rows ...
+  int i_newrow0 = 0;                 // ... key j is row i_newrow0 + j of them
 
   auto cursor_to = [&](const i32x4& a0, const i32x4& a1, int src) {
     i_src = src;
@@ -784,6 +842,12 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     i_n = a1.w;
     i_b = a1.x;
     if constexpr (!PAGED) i_krow0 = sload(p.cu_k + a1.x);
+    if constexpr (PAGED && !FP8) {
+      if (p.k_new != nullptr) {
+        i_ctx = a1.w - (sload(p.cu_q + a1.x + 1) - sload(p.cu_q + a1.x));  // seq_len - q_len
+        i_newrow0 = a1.y - a1.z;                                          // first query row - its position
+      }
+    }
   };
   // leave exhausted lists behind
   auto cursor_settle = [&]() {
@@ -816,17 +880,32 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     const int n = i_n;
     {
       const int j0 = d_tile * kBlockN;
-      if (j0 + kBlockN <= n) {
+      // two sources: a tile from the step's own rows, or one that holds the last cached key AND the first new one
+      bool from_new = false, straddle = false;
+      if constexpr (PAGED && !FP8) {
+        from_new = j0 >= i_ctx;
+        straddle = j0 < i_ctx && j0 + kBlockN > i_ctx;
+      }
+      if (j0 + kBlockN <= n && !straddle) {
         // whole tile inside the sequence: one wave-uniform base per 16-key half
-        long long bb;
-        if constexpr (PAGED) {
-          const long long b0 = d_off0 + (long long)(j0 & (p.page_size - 1)) * kv_row_bytes;
-          bb = (iss_second && p.page_size == 16) ? d_off1 - 16ll * kv_row_bytes : b0;
-        } else {
-          bb = (i_krow0 + j0) * kv_row_bytes;
-        }
+        if (from_new) {
+          // rows of the step's key / value tensors: same chunk swizzle, their own row stride
+          const long long bb = (long long)(i_newrow0 + j0) * new_row_bytes;
+          const int lrow = opaque(lane) / KCPR;
 #pragma unroll
-        for (int x = 0; x < PW; ++x) glds16_s(kv_iss + bb, kv_voff[x], dst + x * 1024);
+          for (int x = 0; x < PW; ++x)
+            glds16_s(kn_iss + bb, kv_voff[x] + ((pit0 + x) * KRPP + lrow) * (new_row_bytes - kv_row_bytes), dst + x * 1024);
+        } else {
+          long long bb;
+          if constexpr (PAGED) {
+            const long long b0 = d_off0 + (long long)(j0 & (p.page_size - 1)) * kv_row_bytes;
+            bb = (iss_second && p.page_size == 16) ? d_off1 - 16ll * kv_row_bytes : b0;
+          } else {
+            bb = (i_krow0 + j0) * kv_row_bytes;
+          }
+#pragma unroll
+          for (int x = 0; x < PW; ++x) glds16_s(kv_iss + bb, kv_voff[x], dst + x * 1024);
+        }
       } else {
         // last, partial tile: keys past the end are masked later; clamp their source to the last key
         const int l2 = opaque(lane);
@@ -842,7 +921,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
             off = (i_krow0 + j) * kv_row_bytes;
           }
           const int swz = FP8 ? 0 : (iss_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row));
-          glds16(kv_iss + off + 16 * ((l2 % KCPR) ^ swz), dst + x * 1024);
+          const char* src = kv_iss + off;
+          if constexpr (PAGED && !FP8) {
+            if (j >= i_ctx) src = kn_iss + (long long)(i_newrow0 + j) * new_row_bytes;
+          }
+          glds16(src + 16 * ((l2 % KCPR) ^ swz), dst + x * 1024);
         }
       }
     }
@@ -1606,6 +1689,21 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
     TMX_CHECK_ARG(a->kv_stride_t % 16 == 0 && a->kv_stride_h % 16 == 0 && a->kv_stride_page % 16 == 0,
                   "tmx_attention: fp8 cache strides must be multiples of 16 bytes");
   }
+  const bool two_src = a->k_new != nullptr || a->v_new != nullptr;
+  if (two_src) {
+    TMX_CHECK_ARG(a->k_new != nullptr && a->v_new != nullptr, "tmx_attention: k_new and v_new go together");
+    TMX_CHECK_SUPPORTED(paged && !fp8, "tmx_attention: k_new / v_new need a 16-bit paged cache (an fp8 cache holds other "
+                                       "values than the step's rows)");
+    TMX_CHECK_ARG(aligned16(a->k_new) && aligned16(a->v_new) && a->new_stride_t % 8 == 0 && a->new_stride_h % 8 == 0 &&
+                      a->new_stride_t >= 0 && a->new_stride_h >= 0 && a->new_stride_t < (1ll << 24) &&
+                      a->new_stride_h <= 0x7FFFFFFF,
+                  "tmx_attention: k_new / v_new must be 16-byte aligned with strides that are multiples of 8 elements");
+  }
+  if (a->cache_slots != nullptr) {
+    TMX_CHECK_ARG(two_src, "tmx_attention: cache_slots needs k_new / v_new (the rows to store)");
+    TMX_CHECK_SUPPORTED((long long)a->total_q * a->num_kv_heads * (a->head_dim / 8) < (1ll << 31),
+                        "tmx_attention: too many rows for the fused cache write");
+  }
   if (has_bias)
     TMX_CHECK_ARG((a->bias_dtype == TMX_F32 || a->bias_dtype == TMX_BF16 || a->bias_dtype == TMX_F16) &&
                       a->bias_rows > 0 && a->bias_cols > 0 && a->bias_stride >= a->bias_cols,
@@ -1654,6 +1752,12 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.block_table_stride = (int)a->block_table_stride;
   p.tile_pages = nullptr;
   p.full_lens = ix->full_lens;
+  p.k_new = a->k_new;
+  p.v_new = a->v_new;
+  p.new_stride_t = (int)a->new_stride_t;
+  p.new_stride_h = (int)a->new_stride_h;
+  p.cache_slots = reinterpret_cast<const long long*>(a->cache_slots);
+  p.total_q = a->total_q;
   if (paged && ix->tile_pages != nullptr && ix->pages_block_table == a->block_table &&
       ix->pages_page_size == a->page_size && ix->pages_block_table_stride == a->block_table_stride)
     p.tile_pages = ix->tile_pages;
@@ -1715,6 +1819,12 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
     d.cu_k = a->cu_seqlens_k;
     d.cu_q = a->cu_seqlens_q;
     d.seq_lens = a->seq_lens;
+    d.k_new = a->k_new;
+    d.v_new = a->v_new;
+    d.new_stride_t = p.new_stride_t;
+    d.new_stride_h = p.new_stride_h;
+    d.cache_slots = p.cache_slots;  // the dense kernel, launched first, stores the step's rows
+    p.cache_slots = nullptr;
     d.q_stride_t = p.q_stride_t;
     d.q_stride_h = p.q_stride_h;
     d.out_stride_t = p.out_stride_t;

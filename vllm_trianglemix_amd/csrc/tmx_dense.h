@@ -22,6 +22,10 @@ struct DenseParams {
   const int32_t* cu_k;
   const int32_t* cu_q;
   const int32_t* seq_lens;
+  const void* k_new;  // the step's own K / V rows, or NULL (see tmx_attention_args_t)
+  const void* v_new;
+  int new_stride_t, new_stride_h;
+  const long long* cache_slots;  // fused cache write (see fused_cache_write in tmx_attention.hip), or NULL
   int q_stride_t, q_stride_h, out_stride_t, out_stride_h;  // elements
   int kv_stride_page, kv_stride_t, kv_stride_h, block_table_stride;
   int page_size, page_shift;

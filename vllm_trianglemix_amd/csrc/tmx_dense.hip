@@ -94,6 +94,30 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
   const int hg = wave & 3, rb = wave >> 2;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds));
 
+  // ---- the step's cache write, fused (16-bit cache; the launch reads the step's keys from k_new / v_new) ----
+  if constexpr (PAGED && !KV8) {
+    if (p.cache_slots != nullptr) {
+      const int units = p.total_q * p.Hkv * 16;  // (row, head, 16-byte chunk)
+      const uint16_t* kn = reinterpret_cast<const uint16_t*>(p.k_new);
+      const uint16_t* vn = reinterpret_cast<const uint16_t*>(p.v_new);
+      uint16_t* kc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.k));
+      uint16_t* vc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.v));
+      for (int u = (int)blockIdx.x * 512 + tid; u < units; u += (int)gridDim.x * 512) {
+        const int c = u & 15, th = u >> 4;
+        const int hh = th % p.Hkv, t = th / p.Hkv;
+        const long long slot = p.cache_slots[t];
+        if (slot < 0) continue;
+        const long long src = (long long)t * p.new_stride_t + (long long)hh * p.new_stride_h + 8 * c;
+        const long long dst = (slot >> p.page_shift) * p.kv_stride_page + (slot & (p.page_size - 1)) * (long long)p.kv_stride_t +
+                              (long long)hh * p.kv_stride_h + 8 * c;
+        const uint4 kx = *reinterpret_cast<const uint4*>(kn + src);
+        const uint4 vx = *reinterpret_cast<const uint4*>(vn + src);
+        *reinterpret_cast<uint4*>(kc + dst) = kx;
+        *reinterpret_cast<uint4*>(vc + dst) = vx;
+      }
+    }
+  }
+
   // ---- the launch's work: 64-row blocks of the requests this kernel takes, x K/V head chunks ----
   for (int b = tid; b < p.batch; b += 512) {
     const int q_len = p.cu_q[b + 1] - p.cu_q[b];
@@ -192,11 +216,21 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
       } else {
         off = (krow0 + key) * kv_row_bytes;
       }
-      kreg[0] = *reinterpret_cast<const uint4*>(k_head + off);
-      vreg[0] = *reinterpret_cast<const uint4*>(v_head + off);
+      const char* ksrc = k_head + off;
+      const char* vsrc = v_head + off;
+      if constexpr (PAGED && !KV8) {
+        // two sources: keys from position ctx on are rows of the step's own tensors
+        if (p.k_new != nullptr && key >= ctx) {
+          const long long noff = (long long)(q_start - ctx + key) * (2 * p.new_stride_t) + 2ll * kvh * p.new_stride_h + 32 * sc2;
+          ksrc = reinterpret_cast<const char*>(p.k_new) + noff;
+          vsrc = reinterpret_cast<const char*>(p.v_new) + noff;
+        }
+      }
+      kreg[0] = *reinterpret_cast<const uint4*>(ksrc);
+      vreg[0] = *reinterpret_cast<const uint4*>(vsrc);
       if constexpr (!KV8) {
-        kreg[1] = *reinterpret_cast<const uint4*>(k_head + off + 16);
-        vreg[1] = *reinterpret_cast<const uint4*>(v_head + off + 16);
+        kreg[1] = *reinterpret_cast<const uint4*>(ksrc + 16);
+        vreg[1] = *reinterpret_cast<const uint4*>(vsrc + 16);
       }
     };
     auto stage = [&](unsigned buf, uint4 (&kreg)[2], uint4 (&vreg)[2]) {

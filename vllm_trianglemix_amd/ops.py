@@ -257,9 +257,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
               cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, scale: float,
               cu_seqlens_k: Optional[torch.Tensor] = None, block_table: Optional[torch.Tensor] = None,
               bias: Optional[torch.Tensor] = None, workspace: Optional[Sequence[torch.Tensor]] = None,
-              flags: int = 0, static_workspace: bool = False, k_scale: float = 1.0, v_scale: float = 1.0
-              ) -> torch.Tensor:
+              flags: int = 0, static_workspace: bool = False, k_scale: float = 1.0, v_scale: float = 1.0,
+              k_new: Optional[torch.Tensor] = None, v_new: Optional[torch.Tensor] = None,
+              cache_slots: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Masked attention over the tiles ``index`` lists.
+
+    ``k_new`` / ``v_new`` (paged 16-bit cache): the step's own key / value rows ``[T, Hkv, D]``; every request's
+    keys from position ``seq_len - q_len`` on are read from them instead of the cache, so the call does not
+    depend on this step's cache write.  ``cache_slots`` (int64 ``[T]``, the step's ``slot_mapping``): the
+    same call also stores those rows into the cache (``reshape_and_cache`` fused into the attention launch).
 
     An fp8 (e4m3fn) paged cache (``k``/``v`` of dtype uint8 or float8_e4m3fn, as ``reshape_and_cache_fp8`` writes
     it) is read in place: the kernel descales inside its tile loop with ``k_scale`` / ``v_scale`` (head size 128).
@@ -321,6 +327,24 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     if k.shape[-1] != D:
         raise RuntimeError("k/v head size differs from q")
     a.kv_dtype, a.k_scale, a.v_scale = (_lib.TMX_FP8_E4M3, float(k_scale), float(v_scale)) if fp8 else (0, 1.0, 1.0)
+    if k_new is not None or v_new is not None:
+        if k_new is None or v_new is None or not paged or fp8:
+            raise RuntimeError("k_new and v_new go together and need a 16-bit paged cache")
+        _require_gpu(k_new, "k_new")
+        _require_gpu(v_new, "v_new")
+        if (k_new.dim() != 3 or k_new.shape != v_new.shape or k_new.stride() != v_new.stride() or k_new.stride(2) != 1
+                or k_new.dtype != q.dtype or v_new.dtype != q.dtype or k_new.shape[0] < T
+                or tuple(k_new.shape[1:]) != (a.num_kv_heads, D)):
+            raise RuntimeError("k_new / v_new must be [T, Hkv, D] rows of the q dtype with equal strides")
+        a.k_new, a.v_new, a.new_stride_t, a.new_stride_h = k_new.data_ptr(), v_new.data_ptr(), k_new.stride(0), k_new.stride(1)
+    else:
+        a.k_new, a.v_new, a.new_stride_t, a.new_stride_h = None, None, 0, 0
+    a.cache_slots = None
+    if cache_slots is not None:
+        _require_gpu(cache_slots, "cache_slots")
+        if k_new is None or cache_slots.dtype != torch.int64 or not cache_slots.is_contiguous() or cache_slots.numel() < T:
+            raise RuntimeError("cache_slots must be contiguous int64 [T] and comes with k_new / v_new")
+        a.cache_slots = cache_slots.data_ptr()
     a.cu_seqlens_q, a.seq_lens = cu_seqlens_q.data_ptr(), seq_lens.data_ptr()
     if bias is not None:
         _require_gpu(bias, "bias")
