@@ -247,13 +247,15 @@ typedef struct tmx_attention_args_t {
   const int32_t* cu_seqlens_q; /* (device) [batch + 1] */
   const int32_t* seq_lens;     /* (device) [batch] */
 
-  /* Optional additive bias added to the scaled scores before the softmax,
-   * indexed [position i][key j] and shared by requests and heads
-   * (the attn_mask argument of ascend_trianglemix.py:57,84,96-97). */
+  /* Optional additive bias added to the scaled scores before the softmax (the attn_mask argument of
+   * ascend_trianglemix.py:57,84,96-97, anything that broadcasts to [batch, heads, N, N]): the element for
+   * request b, head h, position i, key j is bias[b * bias_stride_b + h * bias_stride_h + i * bias_stride + j];
+   * a mask shared by requests and / or heads has zero strides there. */
   const void* bias;
   int32_t bias_dtype; /* TMX_F32 / TMX_BF16 / TMX_F16 */
   int64_t bias_stride; /* row stride in elements */
   int32_t bias_rows, bias_cols;
+  int64_t bias_stride_b, bias_stride_h;
 
   const tmx_index_t* index;
   int64_t num_items, num_partials, num_split_qblocks; /* from tmx_index_sizes */
@@ -304,6 +306,21 @@ int tmx_attention(const tmx_attention_args_t* args, void* stream);
 #define TMX_STATIC_WORKSPACE_BYTES (32u << 20)
 size_t tmx_static_workspace_bytes(void);
 int tmx_attention_static_ws(const tmx_attention_args_t* args, void* stream);
+
+/* ------------------------------------------------------------------------
+ * The eager attention of the reference in fp32 (ascend_trianglemix.py:88-106 run with fp32 tensors, the
+ * configuration the reference itself runs on the CPU): out = softmax(q k^T * scale + mask) v, everything in fp32.
+ * q / k / v / out: contiguous [batch, n, num_heads, head_dim] float32 (no grouped heads in this class); the
+ * pattern is given by mode / si / sl / last as for tmx_attention (TMX_MODE_NONE: no mask at all, what the
+ * reference computes up to 2048 tokens); bias (optional): added to the scaled scores, element for (b, h, i, j)
+ * at bias[b * bias_stride_b + h * bias_stride_h + i * bias_stride_i + j] (zero strides broadcast).  A fully
+ * masked row gives NaN, as the reference's softmax does.  A compatibility path on the vector units: sized for
+ * the reference's test shapes, not a fast path (16-bit inputs take tmx_attention).
+ * ---------------------------------------------------------------------- */
+int tmx_eager_attention_f32(const float* q, const float* k, const float* v, float* out, int32_t batch, int32_t n,
+                            int32_t num_heads, int32_t head_dim, float scale, int32_t mode, int32_t si, int32_t sl,
+                            int32_t last, const void* bias, int32_t bias_dtype, int64_t bias_stride_b,
+                            int64_t bias_stride_h, int64_t bias_stride_i, void* stream);
 
 /* ------------------------------------------------------------------------
  * K/V cache write: copies key/value rows of this step into the paged cache,

@@ -1322,3 +1322,73 @@ def test_two_sources_equal_cache_only_and_backend_overlaps_every_step(monkeypatc
         pos = np.arange(s)
         used[torch.from_numpy(bt[b, pos // page].astype(np.int64) * page + pos % page).to(DEV)] = True
     assert torch.equal(results[2][1].view(2, nblk * page, Hkv, D)[:, used], full.view(2, nblk * page, Hkv, D)[:, used])
+
+
+def test_eager_module_fp32_inputs_match_the_reference_outputs(golden_attention):
+    """fp32 inputs to the standalone module (the reference's own CPU configuration runs fp32): everything in fp32
+    on the device, against the reference's fp32 outputs of the golden cases (explicit masks, the per-model helper
+    above and below the 2048-token gate, no mask at all) and the sampled rows of its 2048-token configuration."""
+    import json, os
+    from vllm_trianglemix_amd import AscendTriangleMixAttention, TriangleMixConfig, TriangleMixMaskGenerator
+    meta, arrays = golden_attention
+    for c in meta["cases"]:
+        if c.get("run_dtype"):
+            continue
+        shape = (c["B"], c["N"], c["H"], c["D"])
+        q, k, v = (torch.from_numpy(orc.seeded_normal(c["seed"] * 3 + t, shape)).to(DEV) for t in range(3))
+        cfg = TriangleMixConfig(*c["cfg"], num_triangle_layers=c.get("ntl"))
+        if c["mask"] == "helper":
+            out = AscendTriangleMixAttention(c["H"], c["D"], c["scale"], cfg, layer_idx=c["layer"],
+                                             num_layers=c["num_layers"])(q, k, v)
+        else:
+            am = TriangleMixMaskGenerator(cfg).get_attention_mask(c["N"], 0, DEV, torch.float32,
+                                                                  use_triangle=(c["mask"] == "triangle"))
+            out = AscendTriangleMixAttention(c["H"], c["D"], c["scale"])(q, k, v, attn_mask=am)
+        assert out.dtype == torch.float32 and tuple(out.shape) == shape and out.is_contiguous()
+        err = np.abs(out.cpu().numpy() - arrays[c["name"]]).max()
+        assert err <= 2e-6, (c["name"], err)  # fp32 against fp32: summation order only
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    m0 = json.load(open(os.path.join(gold, "attention_config0.json")))
+    z = np.load(os.path.join(gold, "attention_config0.npz"))
+    N, H, D = m0["N"], m0["H"], m0["D"]
+    q, k, v = (torch.from_numpy(orc.seeded_normal(m0["seed"] * 3 + t, (1, N, H, D))).to(DEV) for t in range(3))
+    am = TriangleMixMaskGenerator(TriangleMixConfig(*m0["cfg"])).get_attention_mask(N, 0, DEV, torch.float32, use_triangle=True)
+    out = AscendTriangleMixAttention(H, D, m0["scale"])(q, k, v, attn_mask=am)
+    assert np.abs(out[0].cpu().numpy()[z["rows"]] - z["out_rows"]).max() <= 2e-6
+    # a fully masked row is NaN, as the reference's softmax over all -inf is
+    am2 = am.clone()
+    am2[7, :] = float("-inf")
+    assert torch.isnan(AscendTriangleMixAttention(H, D, m0["scale"])(q, k, v, attn_mask=am2)[0, 7]).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_eager_module_broadcast_masks(dtype):
+    """attn_mask of every shape that broadcasts to [batch, heads, N, N] (the reference simply adds it,
+    ascend_trianglemix.py:83-84, 96-97): per request, per head, both, a single row vector, with and without
+    the TriangleMix mask on top."""
+    from vllm_trianglemix_amd import AscendTriangleMixAttention, TriangleMixConfig
+    B, N, H, D = 2, 2100, 2, 64
+    rng = np.random.default_rng(42)
+    q, k, v = (orc.seeded_normal(900 + t, (B, N, H, D)) for t in range(3))
+    scale = D ** -0.5
+    cfg = TriangleMixConfig(4, 32, 64, num_triangle_layers=1)
+    for shape in ((B, H, N, N), (B, 1, N, N), (1, H, N, N), (N, N), (1, 1, 1, N)):
+        if dtype == torch.float32 and shape == (B, H, N, N):
+            continue  # (kept small: the other shapes cover both strides)
+        mask = orc.bf16_round(rng.standard_normal(shape).astype(np.float32))
+        mask[rng.random(shape) < 0.2] = -np.inf
+        full = np.broadcast_to(mask.reshape((1,) * (4 - len(shape)) + shape), (B, H, N, N))
+        for with_tri in (False, True):
+            mod = (AscendTriangleMixAttention(H, D, scale, cfg, layer_idx=0, num_layers=2) if with_tri
+                   else AscendTriangleMixAttention(H, D, scale))
+            out = mod(*(torch.from_numpy(x).to(DEV).to(dtype) for x in (q, k, v)), attn_mask=torch.from_numpy(mask).to(DEV))
+            got = out.float().cpu().numpy()
+            rows = [0, 5, 700, N - 70, N - 1]
+            for b in range(B):
+                for h in range(H):
+                    ref = orc.varlen_gqa_attention(q[b][:, h:h + 1], lambda _: k[b][:, h:h + 1], lambda _: v[b][:, h:h + 1],
+                                                   [0, N], [N], scale, "triangle" if with_tri else "none", 4, 32, 64,
+                                                   bias=np.ascontiguousarray(full[b, h]))
+                    e = np.abs(got[b, rows, h] - ref[rows, 0])
+                    ok = np.isnan(ref[rows, 0]) | (e <= (1e-5 if dtype == torch.float32 else ATOL_F32_OUT + np.abs(ref[rows, 0]) * 2.0 ** -8))
+                    assert ok.all(), (shape, with_tri, b, h, np.nanmax(e))

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "tmx_abi_version", "tmx_last_error", "tmx_attention_block_m", "tmx_attention_block_n", "tmx_dense_mask",
     "tmx_replace_neg_inf", "tmx_index_sizes", "tmx_build_block_index", "tmx_attention", "tmx_reshape_and_cache",
     "tmx_reshape_and_cache_fp8", "tmx_gather_dequant_kv_fp8", "tmx_suggest_chunk_tiles",
-    "tmx_attention_static_ws", "tmx_static_workspace_bytes",
+    "tmx_attention_static_ws", "tmx_static_workspace_bytes", "tmx_eager_attention_f32",
 )
 
 
@@ -65,7 +65,7 @@ class AttentionArgs(Structure):
         ("cache_slots", c_void_p),
         ("cu_seqlens_q", c_void_p), ("seq_lens", c_void_p),
         ("bias", c_void_p), ("bias_dtype", c_int32), ("bias_stride", c_int64),
-        ("bias_rows", c_int32), ("bias_cols", c_int32),
+        ("bias_rows", c_int32), ("bias_cols", c_int32), ("bias_stride_b", c_int64), ("bias_stride_h", c_int64),
         ("index", POINTER(Index)),
         ("num_items", c_int64), ("num_partials", c_int64), ("num_split_qblocks", c_int64),
         ("nnz_tiles", c_int64),
@@ -103,6 +103,9 @@ def load() -> ctypes.CDLL:
     lib.tmx_build_block_index.argtypes = [POINTER(Index), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.tmx_attention.argtypes = [POINTER(AttentionArgs), c_void_p]
     lib.tmx_attention_static_ws.argtypes = [POINTER(AttentionArgs), c_void_p]
+    lib.tmx_eager_attention_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                            c_float, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int64,
+                                            c_int64, c_int64, c_void_p]
     lib.tmx_static_workspace_bytes.argtypes = []
     lib.tmx_static_workspace_bytes.restype = ctypes.c_size_t
     lib.tmx_reshape_and_cache.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,

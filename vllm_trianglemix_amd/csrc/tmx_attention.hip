@@ -137,6 +137,7 @@ struct AttnParams {
   int q_stride_t, q_stride_h, out_stride_t, out_stride_h;  // elements; checked to fit 31 bits
   int kv_stride_page, kv_stride_t, kv_stride_h, block_table_stride;
   int64_t bias_stride;
+  int64_t bias_stride_b, bias_stride_h;  // per request / per head offsets of the bias (0: shared)
   int page_size, page_shift;  // page_size is a power of two
   int H, Hkv, G, Gw, gw_shift, block_m;  // Gw = 1 << gw_shift query heads per workgroup
   int Y;                      // units per work item: K/V heads x head chunks
@@ -1067,6 +1068,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     // length of the whole sequence the pattern is meant for (chunked prefill: the complete prompt)
     const int nf = p.full_lens != nullptr ? imax(n, sload(p.full_lens + ca1.x)) : n;
     const int mode = effective_mode(p.mode, nf, p.tri_min_len);
+    // the bias of this request and head (a mask broadcast over requests and heads has zero strides there)
+    const long long bias_base = HAS_BIAS ? (long long)ca1.x * p.bias_stride_b + (long long)head * p.bias_stride_h : 0;
 
     // tile numbers of the first group (clamped reads stay inside the item's list)
     int nt[kGroupMax];
@@ -1145,7 +1148,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
           const int j = jl + c;
           float b = 0.f;
           if (row_valid && j < p.bias_cols && pos_i < p.bias_rows && j <= key_hi)
-            b = kLog2e * load_bias(p.bias, p.bias_dtype, (long long)pos_i * p.bias_stride + j);
+            b = kLog2e * load_bias(p.bias, p.bias_dtype, bias_base + (long long)pos_i * p.bias_stride + j);
           sc[c] = sc[c] * p.scale_log2 + b;
         }
       }
@@ -1246,7 +1249,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
             const int j = jl + 16 * (c >> 2) + (c & 3);
             float b = 0.f;
             if (row_valid && j < p.bias_cols && pos_i < p.bias_rows && j <= key_hi)
-              b = kLog2e * load_bias(p.bias, p.bias_dtype, (long long)pos_i * p.bias_stride + j);
+              b = kLog2e * load_bias(p.bias, p.bias_dtype, bias_base + (long long)pos_i * p.bias_stride + j);
             s[u][c >> 2][c & 3] = s[u][c >> 2][c & 3] * p.scale_log2 + b;
           }
         }
@@ -1706,7 +1709,8 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   }
   if (has_bias)
     TMX_CHECK_ARG((a->bias_dtype == TMX_F32 || a->bias_dtype == TMX_BF16 || a->bias_dtype == TMX_F16) &&
-                      a->bias_rows > 0 && a->bias_cols > 0 && a->bias_stride >= a->bias_cols,
+                      a->bias_rows > 0 && a->bias_cols > 0 && a->bias_stride >= a->bias_cols && a->bias_stride_b >= 0 &&
+                      a->bias_stride_h >= 0,
                   "tmx_attention: bad bias description");
 
   AttnParams p;
@@ -1762,6 +1766,8 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
       ix->pages_page_size == a->page_size && ix->pages_block_table_stride == a->block_table_stride)
     p.tile_pages = ix->tile_pages;
   p.bias_stride = a->bias_stride;
+  p.bias_stride_b = a->bias_stride_b;
+  p.bias_stride_h = a->bias_stride_h;
   p.page_size = paged ? a->page_size : 1;
   p.page_shift = paged ? __builtin_ctz(a->page_size) : 0;
   p.H = a->num_heads;

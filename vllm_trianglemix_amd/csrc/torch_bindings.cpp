@@ -178,9 +178,15 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
   if (bias.has_value()) {
     a.bias = bias->data_ptr();
     a.bias_dtype = dtype_code(*bias);
-    a.bias_stride = bias->stride(0);
-    a.bias_rows = (int32_t)bias->size(0);
-    a.bias_cols = (int32_t)bias->size(1);
+    TORCH_CHECK(bias->dim() == 2 || bias->dim() == 4, "trianglemix: bias must be [rows, cols] or [1|B, 1|H, rows, cols]");
+    const int64_t d0 = bias->dim() - 2;
+    a.bias_stride = bias->stride(d0);
+    a.bias_rows = (int32_t)bias->size(d0);
+    a.bias_cols = (int32_t)bias->size(d0 + 1);
+    if (bias->dim() == 4) {
+      a.bias_stride_b = bias->size(0) > 1 ? bias->stride(0) : 0;
+      a.bias_stride_h = bias->size(1) > 1 ? bias->stride(1) : 0;
+    }
   }
   a.index = &ix;
   a.num_items = num_items;

@@ -67,8 +67,10 @@ class AscendTriangleMixAttention(nn.Module):
                                f"{tuple(query.shape)} (this class has no grouped heads)")
         if not query.is_cuda:
             raise RuntimeError("AscendTriangleMixAttention runs on HIP devices only (no CPU fallback)")
-        if query.dtype not in (torch.bfloat16, torch.float16):
-            raise NotImplementedError(f"inputs must be bfloat16 or float16, got {query.dtype}")
+        if query.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+            raise NotImplementedError(f"inputs must be float32, bfloat16 or float16, got {query.dtype}")
+        if key.dtype != query.dtype or value.dtype != query.dtype:
+            raise RuntimeError("query, key and value must share a dtype")
         batch, seq_len, heads, dim = query.shape
 
         mode, pattern = "none", (0, 0, 0)
@@ -78,17 +80,25 @@ class AscendTriangleMixAttention(nn.Module):
                 mode, pattern = "triangle", self.trianglemix_attn.config.pattern()
             elif kind == "dense":
                 mode = "causal"
+        if query.dtype == torch.float32:
+            # fp32 inputs, as the reference's own CPU runs: everything in fp32 (no index, one wave per row)
+            return ops.eager_attention_f32(query, key, value, self.scale, ops.MODES[mode], *pattern, bias=attn_mask)
         bias = None
         if attn_mask is not None:
+            # anything that broadcasts to [batch, heads, seq_len, seq_len] (ascend_trianglemix.py:83-84, 96-97)
             bias = attn_mask
-            while bias.dim() > 2 and bias.shape[0] == 1:
-                bias = bias[0]
-            if bias.dim() != 2 or bias.shape[0] != seq_len or bias.shape[1] != seq_len:
-                raise NotImplementedError("attn_mask must broadcast from [seq_len, seq_len]")
+            if bias.dim() > 4 or bias.dim() < 2:
+                raise RuntimeError("attn_mask must broadcast to [batch, heads, seq_len, seq_len]")
+            while bias.dim() < 4:
+                bias = bias[None]
+            if (bias.shape[0] not in (1, batch) or bias.shape[1] not in (1, heads) or bias.shape[2] not in (1, seq_len)
+                    or bias.shape[3] not in (1, seq_len)):
+                raise RuntimeError(f"attn_mask shape {tuple(attn_mask.shape)} does not broadcast to "
+                                   f"[{batch}, {heads}, {seq_len}, {seq_len}]")
             if bias.dtype not in (torch.float32, torch.bfloat16, torch.float16):
                 bias = bias.float()
-            if bias.stride(1) != 1:
-                bias = bias.contiguous()
+            if bias.shape[2] != seq_len or bias.shape[3] != seq_len or bias.stride(3) != 1:
+                bias = bias.expand(bias.shape[0], bias.shape[1], seq_len, seq_len).contiguous()
 
         idx, cu, sl = self._index(mode, batch, seq_len, query.device, pattern)
         q = query.reshape(batch * seq_len, heads, dim)

@@ -277,7 +277,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     ``q``/``out``: ``[T, H, D]`` (last dim contiguous).  Contiguous K/V:
     ``k``/``v`` ``[rows, Hkv, D]`` + ``cu_seqlens_k``.  Paged K/V: ``k``/``v``
     ``[num_blocks, page_size, Hkv, D]`` + ``block_table`` ``[B, max_blocks]`` int32.
-    ``bias``: optional additive ``[rows >= max position + 1, cols >= max seq_len]``.
+    ``bias``: optional additive ``[rows >= max position + 1, cols >= max seq_len]``, or 4-D
+    ``[1|batch, 1|heads, rows, cols]`` (per request and / or per head).
     """
     for t, name in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (cu_seqlens_q, "cu_seqlens_q"),
                     (seq_lens, "seq_lens")):
@@ -348,12 +349,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     a.cu_seqlens_q, a.seq_lens = cu_seqlens_q.data_ptr(), seq_lens.data_ptr()
     if bias is not None:
         _require_gpu(bias, "bias")
-        if bias.dim() != 2 or bias.stride(1) != 1:
-            raise RuntimeError("bias must be 2-D with contiguous rows")
-        a.bias, a.bias_dtype, a.bias_stride = bias.data_ptr(), dtype_code(bias.dtype), bias.stride(0)
-        a.bias_rows, a.bias_cols = bias.shape
+        if bias.dim() == 2:
+            bias = bias[None, None]
+        if bias.dim() != 4 or bias.stride(3) != 1 or bias.shape[0] not in (1, index.batch) or bias.shape[1] not in (1, H):
+            raise RuntimeError("bias must be [rows, cols] or [1|batch, 1|heads, rows, cols] with contiguous rows")
+        a.bias, a.bias_dtype, a.bias_stride = bias.data_ptr(), dtype_code(bias.dtype), bias.stride(2)
+        a.bias_rows, a.bias_cols = bias.shape[2], bias.shape[3]
+        a.bias_stride_b = bias.stride(0) if bias.shape[0] > 1 else 0
+        a.bias_stride_h = bias.stride(1) if bias.shape[1] > 1 else 0
     else:
         a.bias, a.bias_dtype, a.bias_stride, a.bias_rows, a.bias_cols = None, 0, 0, 0, 0
+        a.bias_stride_b = a.bias_stride_h = 0
     a.index = ctypes.pointer(index.c)
     sz = index.sizes
     a.num_items, a.num_partials, a.num_split_qblocks = sz.num_items, sz.num_partials, sz.num_split_qblocks
@@ -375,6 +381,33 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
         lib = _lib.load()
         entry = lib.tmx_attention_static_ws if static_workspace else lib.tmx_attention
         check(entry(ctypes.byref(a), _stream(q.device)))
+    return out
+
+
+def eager_attention_f32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, mode: int, si: int = 0,
+                        sl: int = 0, last: int = 0, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``softmax(q k^T * scale + mask) v`` in fp32 on contiguous ``[B, N, H, D]`` float32 tensors (the reference's
+    eager attention run with fp32 inputs, ascend_trianglemix.py:88-106).  ``bias``: anything that broadcasts to
+    ``[B, H, N, N]``."""
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        _require_gpu(t, name)
+    if q.dim() != 4 or q.dtype != torch.float32 or k.shape != q.shape or v.shape != q.shape or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError("q, k, v must be float32 [B, N, H, D] of one shape")
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    B, N, H, D = q.shape
+    out = torch.empty_like(q)
+    bptr, bdt, sb, sh, si_ = None, 0, 0, 0, 0
+    if bias is not None:
+        _require_gpu(bias, "bias")
+        if bias.dtype not in _DTYPE:
+            bias = bias.float()
+        bias = torch.broadcast_to(bias, (B, H, N, N)) if tuple(bias.shape) != (B, H, N, N) else bias
+        if bias.stride(3) != 1 and N > 1:
+            bias = bias.contiguous()
+        bptr, bdt, sb, sh, si_ = bias.data_ptr(), dtype_code(bias.dtype), bias.stride(0), bias.stride(1), bias.stride(2)
+    with torch.cuda.device(q.device):
+        check(_lib.load().tmx_eager_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, N, H, D, float(scale), int(mode),
+                                                  si, sl, last, bptr, bdt, sb, sh, si_, _stream(q.device)))
     return out
 
 
