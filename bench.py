@@ -268,8 +268,8 @@ def main():
     torch.cuda.set_device(dev)
 
     from vllm_trianglemix_amd import ops
-    from vllm_trianglemix_amd._lib import (TMX_ATTN_NO_BAND, TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES,
-                                           TMX_ATTN_SKIP_COMBINE)
+    from vllm_trianglemix_amd._lib import (TMX_ATTN_DECODE_ONLY, TMX_ATTN_NO_BAND, TMX_ATTN_ONLY_COMBINE,
+                                           TMX_ATTN_SHORT_QUERIES, TMX_ATTN_SKIP_COMBINE)
     base_flags = TMX_ATTN_NO_BAND if args.no_band else 0
     from vllm_trianglemix_amd.parallel import RowParallelOutputProjection, shard_heads
 
@@ -452,10 +452,12 @@ def main():
             idx_d = ops.build_block_index(cu_d, sl_d, cu_dh, sl_dh, si, sl, last, bm, bn, ops.MODES["triangle"],
                                           chunk_tiles=chunk_d, block_table=btd, page_size=PAGE)
             work_d = ops.alloc_workspace(idx_d, H, D, dev)
+            # the flags the backend passes for a step of one-row requests: the decode kernel runs alone
+            dec_flags = TMX_ATTN_SHORT_QUERIES | TMX_ATTN_DECODE_ONLY
 
             def decode():
                 ops.attention(qd, kcd, vcd, outd, idx_d, cu_d, sl_d, scale, block_table=btd, workspace=work_d,
-                              flags=TMX_ATTN_SHORT_QUERIES)
+                              flags=dec_flags)
 
             for _ in range(5):
                 decode()
@@ -471,7 +473,7 @@ def main():
 
             def decode8():
                 ops.attention(qd, k8, v8, outd, idx_d, cu_d, sl_d, scale, block_table=btd, workspace=work_d,
-                              flags=TMX_ATTN_SHORT_QUERIES)
+                              flags=dec_flags)
 
             for _ in range(5):
                 decode8()

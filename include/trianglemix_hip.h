@@ -288,6 +288,14 @@ typedef struct tmx_attention_args_t {
  * otherwise computes the requests with 17 query rows or more is not launched).  Same results within the
  * tolerance of the attention (the two kernels sum in different orders). */
 #define TMX_ATTN_NO_DENSE 16u
+/* Measurement aid: one-row requests stay on the work list (the decode kernel that otherwise computes the
+ * one-row requests whose row is dense is not launched).  Same results within the tolerance of the attention. */
+#define TMX_ATTN_NO_DECODE 32u
+/* Hint from a caller that knows its batch (vLLM's max_query_len == 1): EVERY request of the step has exactly
+ * one query row.  The work-list kernel is then not launched at all when the decode kernel covers the step
+ * (head size 128, no bias, a causal or unmasked launch or a pattern with last >= 2 and no full_lens).  A step
+ * that sets it with a longer request in the batch leaves that request's rows unwritten. */
+#define TMX_ATTN_DECODE_ONLY 64u
 
 int tmx_attention(const tmx_attention_args_t* args, void* stream);
 

@@ -1182,6 +1182,105 @@ def test_dense_causal_kernel_matches_oracle_and_work_list(case):
     assert np.all(np.abs(plain - ref) <= tol), np.abs(plain - ref).max()
 
 
+@pytest.mark.parametrize("case", [
+    dict(H=8, Hkv=2, mode="triangle", paged=True, page=16, chunk=4),               # many pieces per row
+    dict(H=32, Hkv=8, mode="triangle", paged=True, page=64, chunk=128),            # Qwen3-8B heads, one piece
+    dict(H=16, Hkv=2, mode="causal", paged=False, chunk=8, dtype=torch.float16),   # two head chunks per K/V head
+    dict(H=4, Hkv=1, mode="none", paged=True, page=32, chunk=16, out=torch.bfloat16),
+    dict(H=8, Hkv=2, mode="triangle", paged=False, chunk=64, gate=2048, out=torch.float16, dtype=torch.float16),
+    dict(H=8, Hkv=2, mode="triangle", paged=True, page=16, chunk=8, mixed=True),   # prompts in the same step
+])
+def test_decode_kernel_matches_oracle_and_work_list(case):
+    """One-row requests whose row is dense (the decode rows of the pattern, every row of a causal or unmasked
+    launch) run on the decode kernel: K/V straight to registers, 16 partial sums per workgroup merged at the
+    end, pieces of long rows through the partial slots.  Same results as the oracle and as the same launch
+    kept on the work list (TMX_ATTN_NO_DECODE); lengths around the 16-key groups, the 32-key tiles and the
+    pieces' ends; with and without the caller's all-decode hint."""
+    from vllm_trianglemix_amd._lib import TMX_ATTN_DECODE_ONLY, TMX_ATTN_NO_DECODE
+    ops = _ops()
+    H, Hkv, D = case["H"], case["Hkv"], 128
+    seq_lens = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 700, 1023, 2049, 3000, 4100]
+    q_lens = [1] * len(seq_lens)
+    if case.get("mixed"):
+        seq_lens += [300, 2500]
+        q_lens += [300, 70]
+    dtype, out_dtype = case.get("dtype", torch.bfloat16), case.get("out", torch.float32)
+    q, ks, vs = _rand_case(8128 + H, q_lens, seq_lens, H, Hkv, D)
+    if dtype == torch.float16:
+        q, ks, vs = (np.float16(q).astype(np.float32), [np.float16(k).astype(np.float32) for k in ks],
+                     [np.float16(v).astype(np.float32) for v in vs])
+    # one key far above the others early in a long row: the running maximum must move, then stay
+    ks[19][40] = 3.0 * q[19, ::H // Hkv]
+    ks = [orc.bf16_round(k) if dtype == torch.bfloat16 else np.float16(k).astype(np.float32) for k in ks]
+    scale = D ** -0.5
+    mode, gate = case["mode"], case.get("gate", 0)
+    pat = (4, 32, 64) if mode == "triangle" else (0, 0, 0)
+    kw = dict(dtype=dtype, out_dtype=out_dtype, paged=case["paged"], page_size=case.get("page", 16), chunk=case["chunk"],
+              gate=gate)
+    cu = np.concatenate([[0], np.cumsum(q_lens)])
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu, seq_lens, scale, mode, *pat, tri_min_len=gate)
+    tol = ATOL_F32_OUT + (np.abs(ref) * 2.0 ** -8 if out_dtype != torch.float32 else 0.0)
+    variants = [("decode kernel", 0), ("work list", TMX_ATTN_NO_DECODE)]
+    if not case.get("mixed"):
+        variants.append(("decode kernel alone", TMX_ATTN_DECODE_ONLY))
+    for name, flags in variants:
+        got = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, mode, pat, flags=flags, **kw)
+        assert not np.isnan(got).any(), name
+        err = np.abs(got - ref)
+        print(f"{name}: max abs err {err.max():.2e}")
+        assert np.all(err <= tol), (name, err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("scales", [(1.0, 1.0), (0.75, 1.5)])
+def test_decode_kernel_fp8_cache(dtype, scales):
+    """Decode rows out of an fp8 (e4m3fn) cache: the decode kernel converts in registers (unit scales: the
+    exact conversion instruction; other scales: value = fp8 x scale rounded once to the 16-bit type).  Checked
+    against the oracle on the dequantised values and against the work-list kernel's conversion stage."""
+    from vllm_trianglemix_amd._lib import TMX_ATTN_DECODE_ONLY, TMX_ATTN_NO_DECODE
+    ops = _ops()
+    H, Hkv, D, page = 16, 2, 128, 16
+    k_scale, v_scale = scales
+    seq_lens = [1, 16, 17, 33, 500, 2049, 3333]
+    q_lens = [1] * len(seq_lens)
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else (lambda x: np.float16(x).astype(np.float32))
+    q, ks, vs = _rand_case(515, q_lens, seq_lens, H, Hkv, D)
+    q = rnd(q)
+    ks[4][7, 0, :4] = [400.0, -448.0, 0.0017, -0.002]   # the format's largest values and its subnormals
+    vs[4][9, 1, :4] = [448.0, -300.0, 2.0 ** -9, -2.0 ** -8]
+    B = len(seq_lens)
+    nblk = sum((s + page - 1) // page for s in seq_lens) + 2
+    perm = np.random.default_rng(3).permutation(nblk).astype(np.int32)
+    kc = torch.zeros((nblk, page, Hkv, D), dtype=torch.uint8, device=DEV)
+    vc = torch.zeros_like(kc)
+    bt = np.zeros((B, max((s + page - 1) // page for s in seq_lens)), np.int32)
+    nxt = 0
+    for b, s in enumerate(seq_lens):
+        for pb in range((s + page - 1) // page):
+            bt[b, pb] = perm[nxt]
+            nxt += 1
+        pos = np.arange(s)
+        slots = torch.from_numpy(bt[b, pos // page].astype(np.int64) * page + pos % page).to(DEV)
+        ops.reshape_and_cache_fp8(_to_dev(ks[b], dtype), _to_dev(vs[b], dtype), kc, vc, slots, k_scale, v_scale)
+    btd = torch.from_numpy(bt).to(DEV)
+    seen = lambda x, sc: rnd(orc.fp8_cache_roundtrip(rnd(x), sc).astype(np.float32))
+    kd, vd = [seen(k, k_scale) for k in ks], [seen(v, v_scale) for v in vs]
+    scale = D ** -0.5
+    ref = orc.varlen_gqa_attention(q, lambda b: kd[b], lambda b: vd[b], np.arange(B + 1), seq_lens, scale, "triangle",
+                                   4, 32, 64)
+    idx, cu, sld = _build(ops, q_lens, seq_lens, 4, 32, 64, ops.attention_block_m(H, Hkv), 32, ops.MODES["triangle"], 16,
+                          block_table=btd, page_size=page)
+    for name, flags in (("decode kernel", 0), ("decode kernel alone", TMX_ATTN_DECODE_ONLY), ("work list", TMX_ATTN_NO_DECODE)):
+        out = torch.full((B, H, D), float("nan"), dtype=torch.float32, device=DEV)
+        ops.attention(_to_dev(q, dtype), kc.view(torch.float8_e4m3fn), vc.view(torch.float8_e4m3fn), out, idx, cu, sld,
+                      scale, block_table=btd, flags=flags, k_scale=k_scale, v_scale=v_scale)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert not np.isnan(got).any(), name
+        tol = ATOL_F32_OUT * np.maximum(1.0, np.abs(ref))
+        assert np.all(np.abs(got - ref) <= tol), (name, np.abs(got - ref).max())
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("page", [16, 64])
 def test_fp8_cache_read_in_place(dtype, page):

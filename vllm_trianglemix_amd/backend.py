@@ -170,9 +170,16 @@ def _side_stream(device: torch.device) -> "torch.cuda.Stream":
 
 
 def _step_flags(m: "TriangleMixAttentionMetadata") -> int:
-    """Hints for the attention kernel: a step whose requests all have at most 16 query rows (decode)."""
-    from ._lib import TMX_ATTN_SHORT_QUERIES
-    return TMX_ATTN_SHORT_QUERIES if m.max_query_len <= 16 else 0
+    """Hints for the attention kernel: a step whose requests all have at most 16 query rows (decode), and a
+    step whose requests all have exactly one (then the decode kernel runs alone)."""
+    from ._lib import TMX_ATTN_DECODE_ONLY, TMX_ATTN_SHORT_QUERIES
+    f = m.__dict__.get("_flags")
+    if f is None:
+        f = TMX_ATTN_SHORT_QUERIES if m.max_query_len <= 16 else 0
+        if m.max_query_len == 1 and bool(np.all(np.diff(m.query_start_loc_cpu) == 1)):
+            f |= TMX_ATTN_DECODE_ONLY
+        m.__dict__["_flags"] = f
+    return f
 
 
 class TriangleMixMetadataBuilder(_BuilderBase):

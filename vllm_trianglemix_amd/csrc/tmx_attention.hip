@@ -30,6 +30,7 @@
 // products, and every lane ends with 8 consecutive output columns per store.
 #include "tmx_common.h"
 #include "tmx_dense.h"
+#include "tmx_decode.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -149,6 +150,7 @@ struct AttnParams {
   int n_generic;              // workgroups 0 .. n_generic - 1 walk the work list, the others are band workgroups
   int num_qblocks;            // q-blocks of the batch
   int dense_on;               // requests of kDenseMinRows query rows or more are computed by the dense causal kernel
+  int decode_on;              // one-row requests whose row is dense are computed by the decode kernel
   int exp_mode;               // tuning builds: 1 = work-list workgroups return at once, 2 = band workgroups do
   long long units_total;      // work items x Y
   int mode, si, sl, last, tri_min_len;
@@ -803,10 +805,15 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       if (!ok) return 0;
       a0 = sload(reinterpret_cast<const i32x4*>(p.items) + 2ll * item);
       a1 = sload(reinterpret_cast<const i32x4*>(p.items) + 2ll * item + 1);
-      if (p.dense_on) {
+      if (p.dense_on | p.decode_on) {
+        const int q_len = sload(p.cu_q + a1.x + 1) - sload(p.cu_q + a1.x);
         // causal launch with the dense kernel beside it: only the requests with few query rows are computed here
-        if (sload(p.cu_q + a1.x + 1) - sload(p.cu_q + a1.x) < kDenseMinRows) return 1;
-        continue;
+        if (p.dense_on && q_len >= kDenseMinRows) continue;
+        if (p.decode_on && q_len == 1) {
+          const int nf1 = p.full_lens != nullptr ? imax(a1.w, sload(p.full_lens + a1.x)) : a1.w;
+          if (decode_row(p.mode, p.last, p.tri_min_len, q_len, a1.z, nf1)) continue;  // the decode kernel's
+        }
+        if (p.dense_on) return 1;
       }
       if (!p.band_on || a0.w >= 0) return 1;  // (pieces of split q-blocks never take the band path)
       const int nf = p.full_lens != nullptr ? imax(a1.w, sload(p.full_lens + a1.x)) : a1.w;
@@ -1855,12 +1862,77 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
     const int rc = launch_dense_causal(d, a->io_dtype == TMX_BF16, paged, s);
     if (rc != TMX_OK) return rc;
   }
-  if (a->io_dtype == TMX_BF16) {
-    if (a->head_dim == 128) return launch<Bf16Traits, 128>(p, paged, has_bias, fp8, a->num_split_qblocks, a->flags, s);
-    return launch<Bf16Traits, 64>(p, paged, has_bias, fp8, a->num_split_qblocks, a->flags, s);
+  // Decode kernel: one-row requests whose row is dense (every decode step of the default pattern, every row of
+  // a causal layer) stream their K/V straight into registers there.  A step of one-row requests only is all
+  // the kernel's; in a mixed step its grid also covers the other requests' items (workgroups that return at
+  // once), which pays only while that grid is small.
+  p.decode_on = 0;
+  uint32_t flags = a->flags;
+  {
+    const int Yd = a->num_kv_heads * (G / 4 > 0 ? G / 4 : 1);
+    const bool shape_ok = !has_bias && G % 4 == 0 && a->head_dim == 128 && (!paged || a->page_size >= 16) &&
+                          (a->mode != TMX_MODE_TRIANGLE || a->last >= 2) &&
+                          !(a->flags & (TMX_ATTN_NO_DECODE | TMX_ATTN_ONLY_COMBINE));
+    const bool pure = a->total_q == a->batch;
+    if (shape_ok && (pure || (a->batch >= 2 && (long long)a->num_items * Yd <= kDecodeMaxMixedGrid))) p.decode_on = 1;
+    if (p.decode_on) {
+      DecodeParams d;
+      d.q = a->q;
+      d.out = a->out;
+      d.k = a->k;
+      d.v = a->v;
+      d.block_table = a->block_table;
+      d.cu_k = a->cu_seqlens_k;
+      d.cu_q = a->cu_seqlens_q;
+      d.full_lens = p.full_lens;
+      d.items = p.items;
+      d.col_idx = p.col_idx;
+      d.partial_o = p.partial_o;
+      d.partial_ml = p.partial_ml;
+      d.k_new = a->k_new;
+      d.v_new = a->v_new;
+      d.cache_slots = p.cache_slots;  // launched first, the decode kernel stores the step's rows
+      p.cache_slots = nullptr;
+      d.new_stride_t = p.new_stride_t;
+      d.new_stride_h = p.new_stride_h;
+      d.total_q = a->total_q;
+      d.q_stride_t = p.q_stride_t;
+      d.q_stride_h = p.q_stride_h;
+      d.out_stride_t = p.out_stride_t;
+      d.out_stride_h = p.out_stride_h;
+      d.kv_stride_page = p.kv_stride_page;
+      d.kv_stride_t = p.kv_stride_t;
+      d.kv_stride_h = p.kv_stride_h;
+      d.block_table_stride = p.block_table_stride;
+      d.page_size = p.page_size;
+      d.page_shift = p.page_shift;
+      d.H = p.H;
+      d.Hkv = p.Hkv;
+      d.G = G;
+      d.Y = Yd;
+      d.block_m = p.block_m;
+      d.num_items = p.num_items;
+      d.mode = p.mode;
+      d.last = p.last;
+      d.tri_min_len = p.tri_min_len;
+      d.out_dtype = a->out_dtype;
+      d.scale_log2 = p.scale_log2;
+      d.kv_fp8 = fp8 ? 1 : 0;
+      d.k_scale = p.k_scale;
+      d.v_scale = p.v_scale;
+      const int rc = launch_decode(d, a->io_dtype == TMX_BF16, paged, s);
+      if (rc != TMX_OK) return rc;
+      // every request has one row and every such row is dense: nothing is left for the work-list kernel
+      const bool all_dense_rows = a->mode != TMX_MODE_TRIANGLE || (a->last >= 2 && p.full_lens == nullptr);
+      if ((a->flags & TMX_ATTN_DECODE_ONLY) && pure && all_dense_rows) flags |= TMX_ATTN_ONLY_COMBINE;
+    }
   }
-  if (a->head_dim == 128) return launch<F16Traits, 128>(p, paged, has_bias, fp8, a->num_split_qblocks, a->flags, s);
-  return launch<F16Traits, 64>(p, paged, has_bias, fp8, a->num_split_qblocks, a->flags, s);
+  if (a->io_dtype == TMX_BF16) {
+    if (a->head_dim == 128) return launch<Bf16Traits, 128>(p, paged, has_bias, fp8, a->num_split_qblocks, flags, s);
+    return launch<Bf16Traits, 64>(p, paged, has_bias, fp8, a->num_split_qblocks, flags, s);
+  }
+  if (a->head_dim == 128) return launch<F16Traits, 128>(p, paged, has_bias, fp8, a->num_split_qblocks, flags, s);
+  return launch<F16Traits, 64>(p, paged, has_bias, fp8, a->num_split_qblocks, flags, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,389 @@
+// Decode rows for gfx950 (MI355X): a request with ONE query row whose row is dense -- every decode step of the
+// reference's pattern is (the last row always lies among the trailing rows, N - i < last,
+// vllm/attention/trianglemix_attention.py:126-129) and so is every row of a causal layer.  Such a row reads all
+// of its K/V once and does almost no arithmetic: the work-list kernel's LDS ring, barriers and 16-row tiles
+// buy nothing there.  This kernel streams K/V straight from memory into registers:
+//
+//   workgroup = 4 waves = one work item (a piece of a request's key range) x 4 query heads of one K/V head;
+//   the waves take the piece's 32-key tiles in turn and never synchronise until the end.
+//   Per 16 keys and wave: K rows arrive in the A layout of v_mfma_f32_16x16x32 (lane = key, 16 bytes of the
+//   row per k-step), the 4 query heads are 4 of the 16 B columns, so 4 matrix instructions give all scores;
+//   V rows arrive as 16 bytes per lane (lane group g of 16 lanes = key 4 g + i of step i, lane = 8 head-dim
+//   columns); the probabilities reach those lanes by ds_bpermute (16 per 16 keys) and the weighted sum runs on
+//   the vector units in fp32.  The next 16 keys' 8 loads per lane are in flight while a group is computed.
+//   An fp8 (e4m3fn) cache is read at half the bytes and descaled in registers: value = fp8 x scale, rounded
+//   once to the 16-bit type (vllm/v1/attention/backends/rocm_attn.py:421-422).
+//   At the end the 16 partial results of a workgroup (4 waves x 4 lane groups) merge through LDS into the
+//   output row, or into the piece's partial slot for the combine pass of the work-list kernel's launch.
+#include <type_traits>
+
+#include "tmx_common.h"
+#include "tmx_decode.h"
+
+namespace tmx {
+
+typedef __attribute__((ext_vector_type(4))) float dc_f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 dc_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 dc_f16x8;
+typedef __attribute__((ext_vector_type(4))) int dc_i32x4;
+typedef __attribute__((ext_vector_type(2))) float dc_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 dc_bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 dc_f16x2;
+
+constexpr float kDcMinusBig = -1.0e30f;
+constexpr float kDcSlack = 8.0f;
+
+template <typename T>
+__device__ __forceinline__ T dcs(const T* ptr) {
+  return *reinterpret_cast<const __attribute__((address_space(4))) T*>((const __attribute__((address_space(4))) void*)ptr);
+}
+
+template <bool BF16>
+__device__ __forceinline__ uint32_t dc_pack(float a, float b) {
+  if constexpr (BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(dc_f32x2{a, b}, dc_bf16x2));
+  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(dc_f32x2{a, b}, dc_f16x2));
+}
+// the two 16-bit values of a dword as floats
+template <bool BF16>
+__device__ __forceinline__ void dc_unpack(uint32_t w, float& lo, float& hi) {
+  if constexpr (BF16) {
+    lo = __uint_as_float(w << 16);
+    hi = __uint_as_float(w & 0xffff0000u);
+  } else {
+    const dc_f16x2 h = __builtin_bit_cast(dc_f16x2, w);
+    lo = (float)h[0];
+    hi = (float)h[1];
+  }
+}
+
+template <bool BF16, bool PAGED, bool KV8, bool UNIT>
+__global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
+  constexpr int D = 128;
+  constexpr int KVB = KV8 ? 1 : 2;
+  __shared__ float part_o[16][4][D];   // [wave * 4 + lane group][head][column]
+  __shared__ float part_ml[16][4][2];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g = lane >> 4;
+
+  if (p.cache_slots != nullptr) {
+    // The cache write of the step (the reference's reshape_and_cache_flash, csrc/cache_kernels.cu:282-355),
+    // shared out over the launch's threads.  Nothing in this launch reads those slots: the step's own keys
+    // come from k_new / v_new.
+    constexpr int CPR = D / 8;  // 16-byte chunks per row of one head
+    const int units = p.total_q * p.Hkv * CPR;
+    const int stride = (int)gridDim.x * 256;
+    const uint16_t* kn = reinterpret_cast<const uint16_t*>(p.k_new);
+    const uint16_t* vn = reinterpret_cast<const uint16_t*>(p.v_new);
+    uint16_t* kc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.k));
+    uint16_t* vc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.v));
+    for (int u = (int)blockIdx.x * 256 + tid; u < units; u += stride) {
+      const int c = u % CPR, th = u / CPR;
+      const int h = th % p.Hkv, t = th / p.Hkv;
+      const long long slot = p.cache_slots[t];
+      if (slot < 0) continue;
+      const long long src = (long long)t * p.new_stride_t + (long long)h * p.new_stride_h + 8 * c;
+      const long long dst = (slot >> p.page_shift) * p.kv_stride_page + (slot & (p.page_size - 1)) * (long long)p.kv_stride_t +
+                            (long long)h * p.kv_stride_h + 8 * c;
+      const uint4 kx = *reinterpret_cast<const uint4*>(kn + src);
+      const uint4 vx = *reinterpret_cast<const uint4*>(vn + src);
+      *reinterpret_cast<uint4*>(kc + dst) = kx;
+      *reinterpret_cast<uint4*>(vc + dst) = vx;
+    }
+  }
+
+  const int item = (int)blockIdx.x / p.Y, kvc = (int)blockIdx.x % p.Y;
+  const dc_i32x4 a0 = dcs(reinterpret_cast<const dc_i32x4*>(p.items) + 2ll * item);
+  const dc_i32x4 a1 = dcs(reinterpret_cast<const dc_i32x4*>(p.items) + 2ll * item + 1);
+  // a0 = (q-block, first entry of col_idx, tiles, partial slot), a1 = (request, query row, position, keys)
+  const int b = a1.x, q_tok = a1.y, pos = a1.z, n = a1.w;
+  {
+    const int q_len = dcs(p.cu_q + b + 1) - dcs(p.cu_q + b);
+    const int nf = p.full_lens != nullptr ? imax(n, dcs(p.full_lens + b)) : n;
+    if (!decode_row(p.mode, p.last, p.tri_min_len, q_len, pos, nf)) return;  // the work-list kernel computes it
+  }
+  const int ntiles = a0.z, slot = a0.w;
+  const int tile0 = ntiles > 0 ? dcs(p.col_idx + a0.y) : 0;  // a dense row's tiles are consecutive
+  const int chunks = p.G / 4;
+  const int kvh = kvc / chunks;
+  const int head0 = kvh * p.G + (kvc - kvh * chunks) * 4;
+  const int key_end = imin(n, pos + 1);  // keys 0 .. key_end - 1 are attended (all n of them when nothing is masked)
+  const int n_att = p.mode == TMX_MODE_NONE ? n : key_end;
+
+  // ---- the query rows of the 4 heads: B operand of S^T = K Q^T, column c16 = head (columns 4..15 zero).
+  // 16-bit K: k-step ks covers columns 32 ks + 8 g .. + 7 of lane group g.  fp8 K is fetched 16 bytes (16
+  // columns) at a time, whose halves feed k-steps 2 j and 2 j + 1: those cover columns 64 j + 16 g + 8 h .. ----
+  uint4 qf[4];
+  {
+    const char* qrow = reinterpret_cast<const char*>(p.q) + 2ll * ((long long)q_tok * p.q_stride_t + (long long)(head0 + (c16 & 3)) * p.q_stride_h);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int col = KV8 ? 64 * (ks >> 1) + 16 * g + 8 * (ks & 1) : 32 * ks + 8 * g;
+      qf[ks] = *reinterpret_cast<const uint4*>(qrow + 2 * col);
+      if (c16 >= 4) qf[ks] = make_uint4(0, 0, 0, 0);
+    }
+  }
+
+  const int kv_row_bytes = KVB * p.kv_stride_t;
+  const char* const kbase = reinterpret_cast<const char*>(p.k) + (long long)KVB * kvh * p.kv_stride_h;
+  const char* const vbase = reinterpret_cast<const char*>(p.v) + (long long)KVB * kvh * p.kv_stride_h;
+  const long long krow0 = PAGED ? 0 : (long long)dcs(p.cu_k + b);
+  const int32_t* const bt = PAGED ? p.block_table + (long long)b * p.block_table_stride : nullptr;
+  // two sources: keys from position ctx on (the step's own row) come from k_new / v_new
+  const bool two = PAGED && !KV8 && p.k_new != nullptr;
+  const int ctx = n - 1;
+  const long long new_off = two ? 2ll * ((long long)q_tok * p.new_stride_t + (long long)kvh * p.new_stride_h) : 0;
+
+  // Raw loads of one 16-key group.  K in the matrix layout: lane = key c16, 16 bytes per load at byte 16 g of
+  // every 64 of the row (16-bit: 4 loads = 4 k-steps; fp8: 2 loads).  V: lane group g holds key 4 g + i in step
+  // i, lane c16 its columns 8 c16 .. + 7 (16 bytes, fp8: 8).
+  constexpr int KL = KV8 ? 2 : 4;
+  using VRaw = std::conditional_t<KV8, uint2, uint4>;
+  struct Raw {
+    uint4 k[KL];
+    VRaw v[4];
+  };
+  // lane offsets inside a group whose 16 keys are consecutive rows
+  const unsigned k_lane = (unsigned)c16 * (unsigned)kv_row_bytes + 16u * g;
+  const unsigned v_lane = (unsigned)(4 * g) * (unsigned)kv_row_bytes + (unsigned)(KVB * 8 * c16);
+  const int cache_keys = two ? ctx : n;  // keys below this position are rows of the cache
+  // The usual group: 16 rows of one page (16-aligned groups, pages of 16 keys or more).  Buffer loads: the
+  // descriptor (scalar registers) holds the group's base, the per-lane offsets never change.
+  auto fetch = [&](int jb, Raw& r) {
+    long long off;
+    if constexpr (PAGED) off = (long long)KVB * dcs(bt + (jb >> p.page_shift)) * p.kv_stride_page + (long long)(jb & (p.page_size - 1)) * kv_row_bytes;
+    else off = (krow0 + jb) * kv_row_bytes;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase + off), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase + off), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int x = 0; x < KL; ++x) r.k[x] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rk, k_lane, 64 * x, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (KV8) r.v[i] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rv, v_lane, i * kv_row_bytes, 0));
+      else r.v[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rv, v_lane, i * kv_row_bytes, 0));
+    }
+  };
+  // A group of the sequence's last tile: keys past the end read the last key (masked in the scores), the
+  // step's own key comes from its row.
+  auto fetch_tail = [&](int jb, Raw& r) {
+    long long page_off = 0;
+    if constexpr (PAGED) page_off = (long long)KVB * dcs(bt + (imin(jb, n - 1) >> p.page_shift)) * p.kv_stride_page;
+    auto row_ptr = [&](const char* base, const void* fresh, int key) -> const char* {
+      const int kk = imin(key, n - 1);
+      if (two && kk >= ctx) return reinterpret_cast<const char*>(fresh) + new_off;
+      if constexpr (PAGED) return base + page_off + (long long)(kk & (p.page_size - 1)) * kv_row_bytes;
+      else return base + (krow0 + kk) * kv_row_bytes;
+    };
+    const char* kr = row_ptr(kbase, p.k_new, jb + c16) + 16 * g;
+#pragma unroll
+    for (int x = 0; x < KL; ++x) r.k[x] = *reinterpret_cast<const uint4*>(kr + 64 * x);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = *reinterpret_cast<const VRaw*>(row_ptr(vbase, p.v_new, jb + 4 * g + i) + KVB * 8 * c16);
+  };
+
+  float m_run = kDcMinusBig, l_run = 0.f;  // of head c16 over the keys of lane group g (lanes c16 < 4)
+  float o[4][8];                            // of the 4 heads, columns 8 c16 .. + 7, over the keys of lane group g
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+    for (int x = 0; x < 8; ++x) o[hh][x] = 0.f;
+  int src_lane[4];  // ds_bpermute byte address of lane (head hh, group g)
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh) src_lane[hh] = 4 * (16 * g + hh);
+
+  // 8 fp8 values (two dwords) as 8 values of the 16-bit type: value = fp8 x scale rounded once; a unit scale
+  // converts exactly (every e4m3 value is a bf16 and an fp16 value)
+  auto k_from_fp8 = [&](uint32_t w0, uint32_t w1) -> uint4 {
+    if constexpr (UNIT) {
+      if constexpr (BF16)
+        return make_uint4(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w0, 1.0f, false)),
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w0, 1.0f, true)),
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w1, 1.0f, false)),
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w1, 1.0f, true)));
+      else
+        return make_uint4(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, false)),
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, true)),
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, false)),
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, true)));
+    } else {
+      const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, true);
+      const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, true);
+      return make_uint4(dc_pack<BF16>(f0[0] * p.k_scale, f0[1] * p.k_scale), dc_pack<BF16>(f1[0] * p.k_scale, f1[1] * p.k_scale),
+                        dc_pack<BF16>(f2[0] * p.k_scale, f2[1] * p.k_scale), dc_pack<BF16>(f3[0] * p.k_scale, f3[1] * p.k_scale));
+    }
+  };
+
+  auto compute = [&](int jb, const Raw& r) {
+    // ---- scores of the 16 keys: register c of lane (head, g) is key jb + 4 g + c ----
+    dc_f32x4 s = dc_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 kf;
+      if constexpr (KV8) kf = (ks & 1) ? k_from_fp8(r.k[ks >> 1].z, r.k[ks >> 1].w) : k_from_fp8(r.k[ks >> 1].x, r.k[ks >> 1].y);
+      else kf = r.k[ks];
+      if constexpr (BF16) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dc_bf16x8, kf), __builtin_bit_cast(dc_bf16x8, qf[ks]), s, 0, 0, 0);
+      else s = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dc_f16x8, kf), __builtin_bit_cast(dc_f16x8, qf[ks]), s, 0, 0, 0);
+    }
+    const int d_hi = n_att - 1 - (jb + 4 * g);  // key offset c is attended iff c <= d_hi
+    float sc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sc[c] = (c <= d_hi) ? s[c] * p.scale_log2 : -__builtin_inff();
+    const float tmax = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+    // the running maximum moves only when a group exceeds it by more than the slack (rare): then the sums of
+    // this head in the lanes that hold them (the whole lane group) are rescaled
+    float alpha = 1.f;
+    if (tmax > m_run + kDcSlack) {
+      alpha = __builtin_amdgcn_exp2f(m_run - tmax);
+      m_run = tmax;
+      l_run *= alpha;
+    }
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+      for (int hh = 0; hh < 4; ++hh) {
+        const float ah = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane[hh], __float_as_int(alpha)));
+#pragma unroll
+        for (int x = 0; x < 8; ++x) o[hh][x] *= ah;
+      }
+    }
+    float pr[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pr[c] = __builtin_amdgcn_exp2f(sc[c] - m_run);
+    l_run += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+    // ---- weighted sum: step i is key jb + 4 g + i, whose probability for head hh is register i of lane (hh, g) ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float vf[8];
+      if constexpr (KV8) {
+        const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)r.v[i].x, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)r.v[i].x, true);
+        const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)r.v[i].y, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)r.v[i].y, true);
+        const float raw8[8] = {f0[0], f0[1], f1[0], f1[1], f2[0], f2[1], f3[0], f3[1]};
+#pragma unroll
+        for (int x = 0; x < 8; x += 2) {
+          if constexpr (UNIT) {
+            vf[x] = raw8[x];
+            vf[x + 1] = raw8[x + 1];
+          } else {
+            dc_unpack<BF16>(dc_pack<BF16>(raw8[x] * p.v_scale, raw8[x + 1] * p.v_scale), vf[x], vf[x + 1]);
+          }
+        }
+      } else {
+        dc_unpack<BF16>(r.v[i].x, vf[0], vf[1]);
+        dc_unpack<BF16>(r.v[i].y, vf[2], vf[3]);
+        dc_unpack<BF16>(r.v[i].z, vf[4], vf[5]);
+        dc_unpack<BF16>(r.v[i].w, vf[6], vf[7]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 4; ++hh) {
+        const float ph = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane[hh], __float_as_int(pr[i])));
+#pragma unroll
+        for (int x = 0; x < 8; ++x) o[hh][x] = __builtin_fmaf(ph, vf[x], o[hh][x]);
+      }
+    }
+  };
+
+  // ---- this wave's tiles: tile0 + wave, + 4, ... of the piece, two 16-key groups each; the loads of a group
+  // are in flight while the group before it is computed.  Only the sequence's last tile can hold keys that are
+  // not plain cache rows (the end of the sequence, the step's own key): it is taken after the loop. ----
+  const int my_tiles = imax(0, (ntiles - wave + 3) / 4);
+  const int first_tile = tile0 + wave;
+  // tiles t with 32 (first_tile + 4 t + 1) <= cache_keys
+  const int full_tiles = cache_keys >> 5;  // tiles 0 .. full_tiles - 1 are whole and in the cache
+  const int nt_fast = imin(my_tiles, full_tiles > first_tile ? (full_tiles - first_tile + 3) / 4 : 0);
+  // NB - 1 groups are in flight while one is computed: the 16-bit cache keeps two 8-KiB groups per wave on
+  // their way, the fp8 cache (half the bytes per group) four
+  constexpr int NB = KV8 ? 4 : 2;
+  Raw r[NB];
+  Raw& ra = r[0];
+  const int ng = 2 * nt_fast;
+  auto gkey = [&](int i) { return 32 * (first_tile + 4 * (i >> 1)) + 16 * (i & 1); };
+#pragma unroll
+  for (int x = 0; x < NB - 1; ++x)
+    if (x < ng) fetch(gkey(x), r[x]);
+#pragma unroll 1
+  for (int i = 0; i < ng; i += NB) {
+#pragma unroll
+    for (int x = 0; x < NB; ++x) {
+      if (i + x + NB - 1 < ng) fetch(gkey(i + x + NB - 1), r[(x + NB - 1) % NB]);
+      if (i + x < ng) compute(gkey(i + x), r[x]);
+    }
+  }
+  if (nt_fast < my_tiles) {
+    const int jb = 32 * (first_tile + 4 * nt_fast);
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      if (jb + 16 * h < n_att || h == 0) {
+        fetch_tail(jb + 16 * h, ra);
+        compute(jb + 16 * h, ra);
+      }
+    }
+  }
+
+  // ---- merge the 16 partial results of the workgroup ----
+  const int pi = wave * 4 + g;
+  if (c16 < 4) {
+    part_ml[pi][c16][0] = m_run;
+    part_ml[pi][c16][1] = l_run;
+  }
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+    for (int x = 0; x < 8; ++x) part_o[pi][hh][8 * c16 + x] = o[hh][x];
+  __syncthreads();
+  {
+    const int hh = tid >> 6;           // head of this thread
+    const int d0 = 2 * (tid & 63);     // its two columns
+    float M = kDcMinusBig;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) M = fmaxf(M, part_ml[x][hh][0]);
+    float L = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const float w = __builtin_amdgcn_exp2f(part_ml[x][hh][0] - M);
+      L += w * part_ml[x][hh][1];
+      o0 += w * part_o[x][hh][d0];
+      o1 += w * part_o[x][hh][d0 + 1];
+    }
+    const int head = head0 + hh;
+    if (slot >= 0) {
+      // piece of a split q-block: row 0 of the q-block's partial slot (merged by the combine pass)
+      const long long prow = ((long long)slot * p.H + head) * p.block_m;
+      *reinterpret_cast<float2*>(p.partial_o + prow * D + d0) = make_float2(o0, o1);
+      if (d0 == 0) *reinterpret_cast<float2*>(p.partial_ml + prow * 2) = make_float2(M, L);
+    } else {
+      const float inv = 1.0f / L;
+      const long long off = (long long)q_tok * p.out_stride_t + (long long)head * p.out_stride_h + d0;
+      if (p.out_dtype == TMX_F32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(p.out) + off) = make_float2(o0 * inv, o1 * inv);
+      else if (p.out_dtype == TMX_BF16) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(p.out) + off) = dc_pack<true>(o0 * inv, o1 * inv);
+      else *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(p.out) + off) = dc_pack<false>(o0 * inv, o1 * inv);
+    }
+  }
+}
+
+int launch_decode(const DecodeParams& p, bool bf16, bool paged, hipStream_t s) {
+  const long long grid = (long long)p.num_items * p.Y;
+  if (grid <= 0) return TMX_OK;
+  TMX_CHECK_SUPPORTED(grid < (1ll << 31), "decode kernel: too many work items");
+  const unsigned gsz = (unsigned)grid;
+  if (p.kv_fp8) {
+    const bool unit = p.k_scale == 1.0f && p.v_scale == 1.0f;
+    if (unit) {
+      if (bf16) decode_kernel<true, true, true, true><<<gsz, 256, 0, s>>>(p);
+      else decode_kernel<false, true, true, true><<<gsz, 256, 0, s>>>(p);
+    } else {
+      if (bf16) decode_kernel<true, true, true, false><<<gsz, 256, 0, s>>>(p);
+      else decode_kernel<false, true, true, false><<<gsz, 256, 0, s>>>(p);
+    }
+  } else if (bf16) {
+    if (paged) decode_kernel<true, true, false, false><<<gsz, 256, 0, s>>>(p);
+    else decode_kernel<true, false, false, false><<<gsz, 256, 0, s>>>(p);
+  } else {
+    if (paged) decode_kernel<false, true, false, false><<<gsz, 256, 0, s>>>(p);
+    else decode_kernel<false, false, false, false><<<gsz, 256, 0, s>>>(p);
+  }
+  TMX_CHECK_HIP(hipGetLastError());
+  return TMX_OK;
+}
+
+}  // namespace tmx
