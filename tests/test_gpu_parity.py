@@ -636,6 +636,46 @@ def test_attention_properties_at_full_size(n, paged, H, Hkv, cache):
             assert np.abs(pr @ vn[:, h // G, :].astype(np.float64) - got[i, h]).max() <= ATOL_F32_OUT, (i, h)
 
 
+@pytest.mark.parametrize("H,Hkv,world", [(16, 4, 2), (16, 2, 4)])  # K/V heads partitioned; K/V heads shared by 2 ranks
+def test_head_shards_through_the_output_projection(H, Hkv, world):
+    """What the ranks of a tensor-parallel group compute, on one GPU one rank after the other: every rank's
+    head shard (qwen3.py:85-98) runs the HIP attention on its slice of Q and its K/V heads and multiplies with
+    its slice of o_proj's input dimension (RowParallelOutputProjection); the sum over ranks -- what the
+    all-reduce forms -- equals the unsharded attention through the whole projection, and the concatenated
+    shard outputs equal the unsharded output bit for bit (heads are independent)."""
+    from vllm_trianglemix_amd.parallel import RowParallelOutputProjection, shard_heads
+    ops = _ops()
+    D, hidden = 128, 256
+    q_lens, seq_lens = [2300, 1, 40], [2300, 700, 2100]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    T, S = sum(q_lens), sum(seq_lens)
+    q = torch.randn((T, H, D), generator=g).to(DEV).bfloat16()
+    k = torch.randn((S, Hkv, D), generator=g).to(DEV).bfloat16()
+    v = torch.randn((S, Hkv, D), generator=g).to(DEV).bfloat16()
+    w = (torch.randn((hidden, H * D), generator=g) * 0.05).to(DEV).float()
+    cu_k = torch.from_numpy(np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)).to(DEV)
+
+    def attend(qs, ks, vs):
+        h, hkv = qs.shape[1], ks.shape[1]
+        idx, cu, sld = _build(ops, q_lens, seq_lens, 4, 32, 64, ops.attention_block_m(h, hkv), 32, ops.MODES["triangle"], 16, 2048)
+        out = torch.full(qs.shape, float("nan"), dtype=torch.float32, device=DEV)
+        ops.attention(qs.contiguous(), ks.contiguous(), vs.contiguous(), out, idx, cu, sld, D ** -0.5, cu_seqlens_k=cu_k)
+        return out
+
+    whole = attend(q, k, v)
+    assert not torch.isnan(whole).any()
+    want = RowParallelOutputProjection(w)(whole)
+    total = torch.zeros_like(want)
+    for rank in range(world):
+        sh = shard_heads(H, Hkv, rank, world)
+        part = attend(q[:, sh.head_slice], k[:, sh.kv_head_slice], v[:, sh.kv_head_slice])
+        # same keys, same order of summation per head: the shard's rows are the whole launch's rows
+        assert torch.equal(part, whole[:, sh.head_slice]), rank
+        w_shard = w[:, sh.head_start * D:(sh.head_start + sh.num_heads) * D]
+        total += RowParallelOutputProjection(w_shard)(part)
+    assert (total - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
+
+
 def test_reshape_and_cache_and_errors():
     ops = _ops()
     from vllm_trianglemix_amd._lib import TmxError
@@ -985,9 +1025,10 @@ def test_fp8_kv_cache_write_gather_and_backend():
     assert np.all(err <= ATOL_F32_OUT + np.abs(ref) * 2.0 ** -8), err.max()
 
 
-def test_torch_library_binding_equals_ctypes_path():
+def test_torch_library_binding_equals_ctypes_path(monkeypatch):
     """torch.ops._trianglemix_C.* (TORCH_LIBRARY registration) drives the same entry points as the
-    ctypes binding: identical index, bit-identical attention output."""
+    ctypes binding: identical index, bit-identical attention output -- called directly, through
+    ops.attention's default route (the operator) and through its ctypes route."""
     from vllm_trianglemix_amd import torch_ops
     ops = _ops()
     C = torch_ops.load()
@@ -1036,10 +1077,17 @@ def test_torch_library_binding_equals_ctypes_path():
     out_t = torch.full(qd.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
     C.trianglemix_attention(out_t, qd, kc, vc, btd, cu, sld, None, index, tile_pages, part_o, part_ml, None,
                             D ** -0.5, si, sl, last, mode, 0, chunk, n_items, n_part, n_split)
+    monkeypatch.setattr(ops, "_BINDING", "torch")  # the default route of ops.attention
+    assert ops._op_binding() is not None
+    out_d = torch.full(qd.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.attention(qd, kc, vc, out_d, ref_idx, cu, sld, D ** -0.5, block_table=btd)
+    monkeypatch.setattr(ops, "_BINDING", "ctypes")
     out_c = torch.full(qd.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
     ops.attention(qd, kc, vc, out_c, ref_idx, cu, sld, D ** -0.5, block_table=btd)
+    monkeypatch.undo()
     torch.cuda.synchronize()
     assert torch.equal(out_t.view(torch.int16), out_c.view(torch.int16))
+    assert torch.equal(out_d.view(torch.int16), out_c.view(torch.int16))
     ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu_h, seq_lens, D ** -0.5, "triangle", si, sl,
                                    last)
     got = out_t.float().cpu().numpy()

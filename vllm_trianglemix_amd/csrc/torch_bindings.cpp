@@ -121,6 +121,14 @@ void build_block_index(std::vector<Tensor> index, const std::optional<Tensor>& t
                               stream_of(cu_seqlens_q)));
 }
 
+// Every tensor that reaches the library as a device pointer must live on the GPU of `ref`.
+void on_gpu(const Tensor& t, const Tensor& ref, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.device() == ref.device(), "trianglemix: ", name, " must be on the HIP device of the query");
+}
+void on_gpu(const std::optional<Tensor>& t, const Tensor& ref, const char* name) {
+  if (t.has_value()) on_gpu(*t, ref, name);
+}
+
 void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const Tensor& value_cache,
                const std::optional<Tensor>& block_table, const Tensor& cu_seqlens_q, const Tensor& seq_lens,
                const std::optional<Tensor>& cu_seqlens_k, std::vector<Tensor> index,
@@ -128,16 +136,47 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
                const std::optional<Tensor>& partial_ml, const std::optional<Tensor>& bias, double scale, int64_t si,
                int64_t sl, int64_t last, int64_t mode, int64_t tri_min_len, int64_t chunk_tiles, int64_t num_items,
                int64_t num_partials, int64_t num_split_qblocks, const std::optional<Tensor>& full_lens,
-               int64_t flags, int64_t nnz_tiles) {
+               int64_t flags, int64_t nnz_tiles, const std::optional<Tensor>& k_new, const std::optional<Tensor>& v_new,
+               const std::optional<Tensor>& cache_slots, double k_scale, double v_scale, int64_t index_block_m,
+               int64_t index_block_n) {
+  TORCH_CHECK(query.is_cuda(), "trianglemix: query must be on a HIP device (there is no CPU path)");
   const DeviceGuard guard(query.device());
-  TORCH_CHECK(query.dim() == 3 && out.dim() == 3, "trianglemix: query / out must be [T, H, D]");
+  TORCH_CHECK(query.dim() == 3 && out.dim() == 3 && query.sizes() == out.sizes(), "trianglemix: query / out must both be [T, H, D]");
   const bool paged = block_table.has_value();
   TORCH_CHECK(key_cache.dim() == (paged ? 4 : 3), "trianglemix: K/V must be [blocks, page, Hkv, D] (paged) or [rows, Hkv, D]");
+  on_gpu(out, query, "out");
+  on_gpu(key_cache, query, "key_cache");
+  on_gpu(value_cache, query, "value_cache");
+  on_gpu(cu_seqlens_q, query, "cu_seqlens_q");
+  on_gpu(seq_lens, query, "seq_lens");
+  on_gpu(block_table, query, "block_table");
+  on_gpu(cu_seqlens_k, query, "cu_seqlens_k");
+  on_gpu(tile_pages, query, "tile_pages");
+  on_gpu(partial_o, query, "partial_o");
+  on_gpu(partial_ml, query, "partial_ml");
+  on_gpu(bias, query, "bias");
+  on_gpu(full_lens, query, "full_lens");
+  on_gpu(k_new, query, "k_new");
+  on_gpu(v_new, query, "v_new");
+  on_gpu(cache_slots, query, "cache_slots");
+  for (const Tensor& t : index) on_gpu(t, query, "index");
+  const bool fp8 = key_cache.element_size() == 1;  // uint8 / float8_e4m3fn: an fp8 cache read in place
+  TORCH_CHECK(fp8 || (key_cache.scalar_type() == query.scalar_type() && value_cache.scalar_type() == query.scalar_type()),
+              "trianglemix: q, k, v must share a dtype of bfloat16 or float16 (or K/V be an fp8 cache)");
+  TORCH_CHECK(!fp8 || (paged && !bias.has_value() && query.size(2) == 128 && value_cache.element_size() == 1),
+              "trianglemix: an fp8 K/V cache is read in place only in the paged layout, with head size 128 and no bias");
+  TORCH_CHECK(key_cache.sizes() == value_cache.sizes() && key_cache.strides() == value_cache.strides(),
+              "trianglemix: k and v must have the same shape and strides");
+  TORCH_CHECK(query.stride(2) == 1 && out.stride(2) == 1 && key_cache.stride(-1) == 1,
+              "trianglemix: the head dimension must be contiguous");
+  TORCH_CHECK(key_cache.size(-1) == query.size(2), "trianglemix: k/v head size differs from q");
   tmx_index_t ix;
   const int64_t hkv = key_cache.size(paged ? 2 : 1);
-  const int64_t block_m = tmx_attention_block_m((int)query.size(1), (int)hkv);
+  // the geometry the index was built with (0: the kernel's own; the library rejects any other)
+  const int64_t block_m = index_block_m > 0 ? index_block_m : tmx_attention_block_m((int)query.size(1), (int)hkv);
   fill_index(ix, index, tile_pages, block_table, paged ? key_cache.size(1) : 0, si, sl, last, block_m,
-             tmx_attention_block_n(), mode, tri_min_len, chunk_tiles, seq_lens.numel(), full_lens);
+             index_block_n > 0 ? index_block_n : tmx_attention_block_n(), mode, tri_min_len, chunk_tiles, seq_lens.numel(),
+             full_lens);
   tmx_attention_args_t a{};
   a.struct_size = sizeof(a);
   a.io_dtype = dtype_code(query);
@@ -164,7 +203,10 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
     a.kv_stride_page = key_cache.stride(0);
     a.kv_stride_t = key_cache.stride(1);
     a.kv_stride_h = key_cache.stride(2);
-    a.block_table = i32(*block_table);
+    TORCH_CHECK(block_table->scalar_type() == at::kInt && block_table->dim() == 2 && block_table->stride(1) == 1 &&
+                    block_table->size(0) >= seq_lens.numel(),
+                "trianglemix: block_table must be int32 [B, max_blocks] with contiguous rows that cover the batch");
+    a.block_table = block_table->data_ptr<int32_t>();
     a.block_table_stride = block_table->stride(0);
     a.page_size = (int32_t)key_cache.size(1);
   } else {
@@ -173,6 +215,32 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
     a.kv_stride_h = key_cache.stride(1);
     a.cu_seqlens_k = i32(*cu_seqlens_k);
   }
+  if (fp8) {
+    a.kv_dtype = TMX_FP8_E4M3;
+    a.k_scale = (float)k_scale;
+    a.v_scale = (float)v_scale;
+  } else {
+    a.k_scale = a.v_scale = 1.0f;
+  }
+  TORCH_CHECK(k_new.has_value() == v_new.has_value(), "trianglemix: k_new and v_new go together");
+  if (k_new.has_value()) {
+    TORCH_CHECK(paged && !fp8, "trianglemix: k_new / v_new need a 16-bit paged cache");
+    TORCH_CHECK(k_new->dim() == 3 && k_new->sizes() == v_new->sizes() && k_new->strides() == v_new->strides() &&
+                    k_new->stride(2) == 1 && k_new->scalar_type() == query.scalar_type() &&
+                    v_new->scalar_type() == query.scalar_type() && k_new->size(0) >= query.size(0) &&
+                    k_new->size(1) == hkv && k_new->size(2) == query.size(2),
+                "trianglemix: k_new / v_new must be [T, Hkv, D] rows of the q dtype with equal strides");
+    a.k_new = k_new->data_ptr();
+    a.v_new = v_new->data_ptr();
+    a.new_stride_t = k_new->stride(0);
+    a.new_stride_h = k_new->stride(1);
+  }
+  if (cache_slots.has_value()) {
+    TORCH_CHECK(k_new.has_value() && cache_slots->scalar_type() == at::kLong && cache_slots->is_contiguous() &&
+                    cache_slots->numel() >= query.size(0),
+                "trianglemix: cache_slots must be contiguous int64 [T] and comes with k_new / v_new");
+    a.cache_slots = cache_slots->data_ptr<int64_t>();
+  }
   a.cu_seqlens_q = i32(cu_seqlens_q);
   a.seq_lens = i32(seq_lens);
   if (bias.has_value()) {
@@ -180,10 +248,13 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
     a.bias_dtype = dtype_code(*bias);
     TORCH_CHECK(bias->dim() == 2 || bias->dim() == 4, "trianglemix: bias must be [rows, cols] or [1|B, 1|H, rows, cols]");
     const int64_t d0 = bias->dim() - 2;
+    TORCH_CHECK(bias->stride(d0 + 1) == 1, "trianglemix: bias rows must be contiguous");
     a.bias_stride = bias->stride(d0);
     a.bias_rows = (int32_t)bias->size(d0);
     a.bias_cols = (int32_t)bias->size(d0 + 1);
     if (bias->dim() == 4) {
+      TORCH_CHECK((bias->size(0) == 1 || bias->size(0) == seq_lens.numel()) && (bias->size(1) == 1 || bias->size(1) == query.size(1)),
+                  "trianglemix: a 4-D bias is [1|batch, 1|heads, rows, cols]");
       a.bias_stride_b = bias->size(0) > 1 ? bias->stride(0) : 0;
       a.bias_stride_h = bias->size(1) > 1 ? bias->stride(1) : 0;
     }
@@ -193,6 +264,13 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
   a.num_partials = num_partials;
   a.num_split_qblocks = num_split_qblocks;
   a.nnz_tiles = nnz_tiles;  // 0: unknown (the library then falls back to the capacity of col_idx)
+  if (num_partials > 0) {
+    const int64_t need = num_partials * query.size(1) * block_m;
+    TORCH_CHECK(partial_o.has_value() && partial_ml.has_value() && partial_o->scalar_type() == at::kFloat &&
+                    partial_ml->scalar_type() == at::kFloat && partial_o->is_contiguous() && partial_ml->is_contiguous() &&
+                    partial_o->numel() >= need * query.size(2) && partial_ml->numel() >= need * 2,
+                "trianglemix: attention workspace too small for this index");
+  }
   a.partial_o = partial_o.has_value() ? partial_o->data_ptr<float>() : nullptr;
   a.partial_ml = partial_ml.has_value() ? partial_ml->data_ptr<float>() : nullptr;
   a.flags = (uint32_t)flags;
@@ -263,7 +341,8 @@ TORCH_LIBRARY(_trianglemix_C, m) {
         "Tensor cu_seqlens_q, Tensor seq_lens, Tensor? cu_seqlens_k, Tensor[] index, Tensor? tile_pages, "
         "Tensor? partial_o, Tensor? partial_ml, Tensor? bias, float scale, int si, int sl, int last, int mode, "
         "int tri_min_len, int chunk_tiles, int num_items, int num_partials, int num_split_qblocks, "
-        "Tensor? full_lens=None, int flags=0, int nnz_tiles=0) -> ()");
+        "Tensor? full_lens=None, int flags=0, int nnz_tiles=0, Tensor? k_new=None, Tensor? v_new=None, "
+        "Tensor? cache_slots=None, float k_scale=1.0, float v_scale=1.0, int index_block_m=0, int index_block_n=0) -> ()");
   m.impl("trianglemix_attention", c10::DispatchKey::CUDA, &attention);
   m.def("trianglemix_reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, "
         "Tensor slot_mapping) -> ()");

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -142,7 +143,7 @@ class BlockIndex:
     arrays are slices of ``buf`` (16-byte aligned starts), made on demand, so a step pays for one
     allocation and one launch sequence."""
     __slots__ = ("buf", "_off", "sizes", "c", "batch", "block_m", "block_n", "mode", "si", "sl", "last",
-                 "chunk_tiles", "tri_min_len", "block_table", "full_lens", "full_lens_cpu")
+                 "chunk_tiles", "tri_min_len", "block_table", "full_lens", "full_lens_cpu", "_op_args")
 
     def __init__(self, buf, off, sizes, c, batch, block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
                  block_table, full_lens, full_lens_cpu):
@@ -151,6 +152,21 @@ class BlockIndex:
         self.si, self.sl, self.last, self.chunk_tiles, self.tri_min_len = si, sl, last, chunk_tiles, tri_min_len
         # kept alive: the C struct points at them
         self.block_table, self.full_lens, self.full_lens_cpu = block_table, full_lens, full_lens_cpu
+        self._op_args = None
+
+    def op_args(self):
+        """(the eight index arrays as the list ``torch.ops._trianglemix_C`` takes, tile_pages or None, the
+        counts num_items / num_partials / num_split_qblocks / nnz_tiles): made once per index."""
+        if self._op_args is None:
+            def arr(name):
+                o, n = self._off[name]
+                return self.buf[o:o + max(n, 1)]  # never empty: the library wants a pointer for every array
+            sz = self.sizes
+            self._op_args = ([arr(n) for n in ("row_ptr", "col_idx", "qb_meta", "part_ptr", "items", "split_qb", "totals",
+                                               "scratch")],
+                             arr("tile_pages") if "tile_pages" in self._off else None,
+                             (int(sz.num_items), int(sz.num_partials), int(sz.num_split_qblocks), int(sz.nnz_tiles)))
+        return self._op_args
 
     def _arr(self, name: str) -> torch.Tensor:
         o, n = self._off[name]
@@ -253,6 +269,27 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
 
 
 # --------------------------------------------------------------------------- attention
+# Which binding of the library `attention` goes through (TRIANGLEMIX_BINDING): "torch" (default) =
+# torch.ops._trianglemix_C.trianglemix_attention, the way the reference calls its own native ops
+# (vllm/_custom_ops.py:153-196); "ctypes" = the C struct filled here.  Same library entry point either way.
+_BINDING = os.environ.get("TRIANGLEMIX_BINDING", "torch")
+_op_ns = None
+
+
+def _op_binding():
+    global _op_ns, _BINDING
+    if _BINDING != "torch":
+        return None
+    if _op_ns is None:
+        from . import torch_ops
+        try:
+            _op_ns = torch_ops.load()
+        except ImportError:
+            _BINDING = "ctypes"  # the operator library is not built: the ctypes binding serves
+            return None
+    return _op_ns
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, index: BlockIndex,
               cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, scale: float,
               cu_seqlens_k: Optional[torch.Tensor] = None, block_table: Optional[torch.Tensor] = None,
@@ -280,6 +317,25 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     ``bias``: optional additive ``[rows >= max position + 1, cols >= max seq_len]``, or 4-D
     ``[1|batch, 1|heads, rows, cols]`` (per request and / or per head).
     """
+    C = None if static_workspace else _op_binding()
+    if C is not None:
+        # the registered operator (csrc/torch_bindings.cpp): the same library call, argument checks in C++,
+        # about half the host time of filling the C struct from Python
+        index_list, tile_pages, (n_items, n_part, n_split, nnz) = index.op_args()
+        part_o = part_ml = None
+        if workspace is not None:
+            part_o, part_ml = workspace
+        elif n_part > 0:
+            part_o, part_ml = alloc_workspace(index, q.shape[1], q.shape[2], q.device)
+        try:
+            C.trianglemix_attention(out, q, k, v, block_table, cu_seqlens_q, seq_lens, cu_seqlens_k, index_list,
+                                    tile_pages if block_table is not None else None, part_o, part_ml, bias, float(scale),
+                                    index.si, index.sl, index.last, index.mode, index.tri_min_len, index.chunk_tiles,
+                                    n_items, n_part, n_split, index.full_lens, int(flags), nnz, k_new, v_new, cache_slots,
+                                    float(k_scale), float(v_scale), index.block_m, index.block_n)
+        except RuntimeError as e:
+            raise _lib.TmxError(-1, str(e)) from None
+        return out
     for t, name in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (cu_seqlens_q, "cu_seqlens_q"),
                     (seq_lens, "seq_lens")):
         _require_gpu(t, name)
