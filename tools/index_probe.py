@@ -11,15 +11,27 @@ for n in [int(x) for x in (sys.argv[1:] or ["8192", "32768", "131072"])]:
     cu, sl = torch.from_numpy(cu_h).to(dev), torch.from_numpy(sl_h).to(dev)
     page = 16
     bt = torch.randperm(n // page).to(torch.int32).view(1, -1).to(dev)
-    idx = ops.build_block_index(cu, sl, cu_h, sl_h, 4, 32, 64, 32, 32, 2, chunk_tiles=64, block_table=bt, page_size=page)
     lib = _lib.load()
-    def run():
-        _lib.check(lib.tmx_build_block_index(ctypes.byref(idx.c), cu.data_ptr(), sl.data_ptr(), None, None, None))
-    for _ in range(5):
-        run()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
-    for a, b in evs:
-        a.record(); run(); b.record()
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in evs)
-    print(f"index build N={n}: med {ts[len(ts)//2]*1e3:.1f} us min {ts[0]*1e3:.1f} us (q-blocks {idx.num_qblocks}, tiles {idx.nnz_tiles})")
+    for pages, host in ((True, False), (False, False), (True, True)):
+        idx = ops.build_block_index(cu, sl, cu_h, sl_h, 4, 32, 64, 32, 32, 2, chunk_tiles=64,
+                                    block_table=bt if pages else None, page_size=page if pages else 0)
+        hc = cu_h.ctypes.data if host else None
+        hs = sl_h.ctypes.data if host else None
+        def run():
+            _lib.check(lib.tmx_build_block_index(ctypes.byref(idx.c), cu.data_ptr(), sl.data_ptr(), hc, hs, None))
+        for _ in range(5):
+            run()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+        for a, b in evs:
+            a.record(); run(); b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        # the same launch 20 times between one pair of events: launch gaps included, event overhead amortised
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"index build N={n} pages={pages} host arrays={host}: med {ts[len(ts)//2]*1e3:.1f} us min {ts[0]*1e3:.1f} us, "
+              f"back to back {e0.elapsed_time(e1) / 20 * 1e3:.1f} us (q-blocks {idx.num_qblocks}, tiles {idx.nnz_tiles})")

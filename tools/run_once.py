@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Runs a few attention launches of one configuration (for rocprofv3 --pmc / --kernel-trace).
 Usage: python tools/run_once.py MODE N [ITERS] [CHUNK] [PAGED]   (MODE: triangle|causal|stream|window;
-PAGED=1: paged K/V cache with 16-token pages and a shuffled block table, as bench.py uses)"""
+PAGED=1: paged K/V cache with 16-token pages and a shuffled block table, as bench.py uses)
+       python tools/run_once.py decode|decode8 KEYS [ITERS] [BATCH]   (one-row requests over KEYS cached tokens each,
+16-bit or fp8 paged cache: the decode kernel alone)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +15,32 @@ paged = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 H, Hkv, D = 32, 8, 128
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
+if mode in ("decode", "decode8"):
+    from vllm_trianglemix_amd._lib import TMX_ATTN_DECODE_ONLY, TMX_ATTN_SHORT_QUERIES
+    B, PAGE = (int(sys.argv[4]) if len(sys.argv) > 4 else 64), 16
+    nblk = B * (n // PAGE)
+    kc = torch.randn((nblk, PAGE, Hkv, D), generator=g).to(dev).bfloat16()
+    vc = torch.randn((nblk, PAGE, Hkv, D), generator=g).to(dev).bfloat16()
+    bt = torch.randperm(nblk, generator=g).to(torch.int32).view(B, -1).to(dev)
+    q = torch.randn((B, H, D), generator=g).to(dev).bfloat16()
+    out = torch.empty_like(q)
+    if mode == "decode8":
+        k8, v8 = torch.zeros(kc.shape, dtype=torch.uint8, device=dev), torch.zeros(kc.shape, dtype=torch.uint8, device=dev)
+        ops.reshape_and_cache_fp8(kc.view(-1, Hkv, D), vc.view(-1, Hkv, D), k8, v8, torch.arange(nblk * PAGE, device=dev), 1.0, 1.0)
+        kc, vc = k8, v8
+    cu_h, sl_h = np.arange(B + 1, dtype=np.int32), np.full((B,), n, np.int32)
+    cu, sl = torch.from_numpy(cu_h).to(dev), torch.from_numpy(sl_h).to(dev)
+    bm = ops.attention_block_m(H, Hkv)
+    c = ops.suggest_chunk_tiles(cu_h, sl_h, 4, 32, 64, bm, 32, ops.MODES["triangle"], ops.units_per_item(H, Hkv))
+    idx = ops.build_block_index(cu, sl, cu_h, sl_h, 4, 32, 64, bm, 32, ops.MODES["triangle"], chunk_tiles=c, block_table=bt,
+                                page_size=PAGE)
+    work = ops.alloc_workspace(idx, H, D, dev)
+    for _ in range(iters):
+        ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=work,
+                      flags=TMX_ATTN_SHORT_QUERIES | TMX_ATTN_DECODE_ONLY)
+    torch.cuda.synchronize()
+    print("done", mode, B, n, idx.sizes.num_items)
+    sys.exit(0)
 q = torch.randn((n, H, D), generator=g).to(dev).bfloat16()
 k = torch.randn((n, Hkv, D), generator=g).to(dev).bfloat16()
 v = torch.randn((n, Hkv, D), generator=g).to(dev).bfloat16()

@@ -93,19 +93,37 @@ __device__ __forceinline__ int first_item_of(int total_pieces, int total_parts, 
 __device__ __forceinline__ void fill_qblock(const IndexParams& p, int qb, int b, int r0, int n, int ctx, int q_row0,
                                             const TileRanges& tr, int cnt, int start, int first_item, int slot0,
                                             int e0, int estep) {
-  for (int e = e0; e < cnt; e += estep)
-    if (start + e < p.cap_nnz) {
-      const int tile = tr.tile_at(e);
-      p.col_idx[start + e] = tile;
-      if (p.tile_pages != nullptr) {
-        // physical pages of the tile's two 16-key halves (keys past the end share the last page)
-        const int32_t* bt = p.block_table + (long long)b * p.block_table_stride;
-        int2 pg;
-        pg.x = bt[(tile * p.block_n) >> p.page_shift];
-        pg.y = bt[imin(tile * p.block_n + 16, n - 1) >> p.page_shift];
-        reinterpret_cast<int2*>(p.tile_pages)[start + e] = pg;
-      }
+  // four entries at a time: their block-table lookups are all in flight before the first store (one trip to
+  // memory per group instead of one per entry)
+  for (int e = e0; e < cnt; e += 4 * estep) {
+    int tile[4];
+    int2 pg[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ee = e + u * estep;
+      ok[u] = ee < cnt && start + ee < p.cap_nnz;
+      tile[u] = ok[u] ? tr.tile_at(ee) : 0;
+      pg[u] = make_int2(0, 0);
     }
+    if (p.tile_pages != nullptr) {
+      // physical pages of the tile's two 16-key halves (keys past the end share the last page)
+      const int32_t* bt = p.block_table + (long long)b * p.block_table_stride;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) {
+          pg[u].x = bt[(tile[u] * p.block_n) >> p.page_shift];
+          pg[u].y = bt[imin(tile[u] * p.block_n + 16, n - 1) >> p.page_shift];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ok[u]) {
+        const int ee = e + u * estep;
+        p.col_idx[start + ee] = tile[u];
+        if (p.tile_pages != nullptr) reinterpret_cast<int2*>(p.tile_pages)[start + ee] = pg[u];
+      }
+  }
   // work items: pieces of one q-block ascending from first_item
   const int pieces = imax(1, ceil_div(cnt, p.chunk));
   for (int pc = e0; pc < pieces; pc += estep) {
