@@ -1,0 +1,132 @@
+"""Seeded random batches through ``tmx_attention`` against the CPU oracle: every combination of request kinds
+(whole prompts, chunks with context, short chunks, decode rows), head groupings, patterns, cache layouts, piece
+lengths and kernel-selection flags must give the oracle's rows -- whichever of the library's kernels computes
+them -- and, when the launch also stores the step's K/V rows, the cache the stand-alone write kernel gives.
+Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import trianglemix_oracle as orc
+from vllm_trianglemix_amd._lib import (TMX_ATTN_NO_BAND, TMX_ATTN_NO_DECODE, TMX_ATTN_NO_DENSE,
+                                       TMX_ATTN_SHORT_QUERIES)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+# fp32 output against the fp64 oracle on the same 16-bit-rounded inputs: 1e-3, absolute up to |ref| = 1 and relative
+# above (a sparse row averages a handful of values and can exceed 1; fp16 probabilities carry 11 bits)
+ATOL = 1e-3
+
+
+def _round(x, dtype):
+    return orc.bf16_round(x) if dtype == torch.bfloat16 else np.float16(x).astype(np.float32)
+
+
+def _random_batch(rng, big):
+    reqs = []
+    for _ in range(int(rng.integers(1, 7))):
+        kind = rng.choice(["decode", "short", "whole", "chunk"], p=[0.35, 0.15, 0.3, 0.2])
+        hi = 3000 if big else 400
+        if kind == "decode":
+            n = int(rng.integers(1, hi))
+            q = 1
+        elif kind == "short":
+            n = int(rng.integers(2, hi))
+            q = int(rng.integers(2, min(n, 40) + 1))
+        elif kind == "whole":
+            n = int(rng.choice([rng.integers(1, hi), rng.integers(2049, 2600) if big else rng.integers(100, 300)]))
+            q = n
+        else:
+            n = int(rng.integers(40, hi))
+            q = int(rng.integers(17, n))
+        reqs.append((q, n))
+    return [r[0] for r in reqs], [r[1] for r in reqs]
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("TMX_FUZZ_SEEDS", "24")))))  # more seeds: a longer hunt
+def test_random_steps_match_the_oracle(seed):
+    from vllm_trianglemix_amd import ops
+    rng = np.random.default_rng(1000 + seed)
+    big = seed % 3 != 0
+    q_lens, seq_lens = _random_batch(rng, big)
+    H, Hkv = [(8, 2), (4, 1), (16, 2), (32, 8), (4, 4), (6, 2), (8, 8)][int(rng.integers(0, 7))]
+    D = 64 if seed % 8 == 7 else 128
+    dtype = torch.float16 if seed % 4 == 1 else torch.bfloat16
+    mode = ["triangle", "triangle", "causal", "none"][int(rng.integers(0, 4))]
+    pat = (4, 32, 64) if rng.random() < 0.6 else (int(rng.integers(-1, 9)), int(rng.integers(0, 41)), int(rng.integers(0, 81)))
+    gate = 2048 if (mode == "triangle" and big and rng.random() < 0.7) else 0
+    chunk = int(rng.choice([2, 4, 16, 64]))
+    paged = rng.random() < 0.7
+    page = int(rng.choice([16, 32, 64]))
+    fused = paged and mode != "none" and rng.random() < 0.5  # the launch stores the step's rows itself
+    flags = 0
+    if max(q_lens) <= 16 and rng.random() < 0.5:
+        flags |= TMX_ATTN_SHORT_QUERIES
+    for f in (TMX_ATTN_NO_BAND, TMX_ATTN_NO_DENSE, TMX_ATTN_NO_DECODE):
+        if rng.random() < 0.25:
+            flags |= f
+
+    T, B = sum(q_lens), len(seq_lens)
+    q = _round(orc.seeded_normal(seed * 7 + 1, (T, H, D)), dtype)
+    ks = [_round(orc.seeded_normal(seed * 7 + 100 + b, (n, Hkv, D)), dtype) for b, n in enumerate(seq_lens)]
+    vs = [_round(orc.seeded_normal(seed * 7 + 200 + b, (n, Hkv, D)), dtype) for b, n in enumerate(seq_lens)]
+    cu_h = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    sl_h = np.asarray(seq_lens, np.int32)
+    cu, sld = torch.from_numpy(cu_h).to(DEV), torch.from_numpy(sl_h).to(DEV)
+    to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV).to(dtype)  # noqa: E731
+    qd = to_dev(q)
+    out = torch.full((T, H, D), float("nan"), dtype=torch.float32, device=DEV)
+    bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
+    scale = D ** -0.5
+    desc = dict(seed=seed, q=q_lens, n=seq_lens, heads=(H, Hkv, D), dtype=str(dtype), mode=mode, pat=pat, gate=gate,
+                chunk=chunk, paged=paged, page=page, fused=fused, flags=flags)
+    if paged:
+        nblk = sum((n + page - 1) // page for n in seq_lens) + 2
+        perm = rng.permutation(nblk).astype(np.int32)
+        kc = torch.zeros((nblk, page, Hkv, D), dtype=dtype, device=DEV)
+        vc = torch.zeros_like(kc)
+        bt = np.zeros((B, max((n + page - 1) // page for n in seq_lens)), np.int32)
+        nxt, new_slots, k_new, v_new = 0, [], [], []
+        for b, n in enumerate(seq_lens):
+            for pb in range((n + page - 1) // page):
+                bt[b, pb] = perm[nxt]
+                nxt += 1
+            pos = np.arange(n)
+            slots = bt[b, pos // page].astype(np.int64) * page + pos % page
+            ctx = n - q_lens[b]
+            old = slice(0, ctx) if fused else slice(0, n)  # with the fused write only the context is in the cache yet
+            if old.stop > 0:
+                ops.reshape_and_cache(to_dev(ks[b][old]), to_dev(vs[b][old]), kc, vc, torch.from_numpy(slots[old]).to(DEV))
+            new_slots.append(slots[ctx:])
+            k_new.append(ks[b][ctx:])
+            v_new.append(vs[b][ctx:])
+        btd = torch.from_numpy(bt).to(DEV)
+        resolve = rng.random() < 0.5
+        idx = ops.build_block_index(cu, sld, cu_h, sl_h, *pat, bm, bn, ops.MODES[mode], chunk_tiles=chunk, tri_min_len=gate,
+                                    block_table=btd if resolve else None, page_size=page if resolve else 0)
+        if fused:
+            kn, vn = to_dev(np.concatenate(k_new, 0)), to_dev(np.concatenate(v_new, 0))
+            slots_d = torch.from_numpy(np.concatenate(new_slots)).to(DEV)
+            ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, flags=flags, k_new=kn, v_new=vn,
+                          cache_slots=slots_d)
+            # the cache now holds every row of every request
+            kf, vf = kc.view(nblk * page, Hkv, D), vc.view(nblk * page, Hkv, D)
+            assert torch.equal(kf[slots_d], kn) and torch.equal(vf[slots_d], vn), desc
+        else:
+            ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, flags=flags)
+    else:
+        idx = ops.build_block_index(cu, sld, cu_h, sl_h, *pat, bm, bn, ops.MODES[mode], chunk_tiles=chunk, tri_min_len=gate)
+        cu_k = torch.from_numpy(np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)).to(DEV)
+        ops.attention(qd, to_dev(np.concatenate(ks, 0)), to_dev(np.concatenate(vs, 0)), out, idx, cu, sld, scale,
+                      cu_seqlens_k=cu_k, flags=flags)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu_h, seq_lens, scale, mode, *pat, tri_min_len=gate)
+    # rows the pattern leaves without any key (a window of 0 keys and no sink, say) are NaN in both
+    both_nan = np.isnan(got) & np.isnan(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), desc
+    err = np.abs(np.where(both_nan, 0.0, got - ref)) / np.maximum(1.0, np.abs(np.nan_to_num(ref)))
+    at = np.unravel_index(err.argmax(), err.shape)
+    assert err.max() <= ATOL, (desc, float(err.max()), at, float(ref[at]), float(got[at]))
