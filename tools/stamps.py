@@ -2,6 +2,8 @@
 """Diagnostic: per-segment cycle shares of the attention loop (needs tools/libtrianglemix_hip_diag.so,
 built with -DTMX_STAMPS).  Usage: TMX_LIB_PATH=tools/libtrianglemix_hip_diag.so python tools/stamps.py MODE N"""
 import os, sys
+os.environ["TMX_STAMPS_BUFFER"] = "1"  # this script's (max, sum) buffer has room for the stamps
+os.environ.setdefault("TRIANGLEMIX_BINDING", "ctypes")  # the library named by TMX_LIB_PATH, not the operator's
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_trianglemix_amd import ops

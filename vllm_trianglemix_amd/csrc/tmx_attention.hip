@@ -1739,8 +1739,10 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.partial_ml = a->partial_ml;
   p.stamps = nullptr;
 #ifdef TMX_STAMPS
-  // diagnostic build: the stamps go to the second half of a (max, sum) buffer of at least 2^20 floats (tools/stamps.py)
-  p.stamps = reinterpret_cast<unsigned long long*>(a->partial_ml + (1 << 19));
+  // diagnostic build: the stamps go to the second half of a (max, sum) buffer of at least 2^21 floats, which only
+  // tools/stamps.py provides -- it says so with TMX_STAMPS_BUFFER=1; any other caller's buffer is left alone
+  if (const char* env = getenv("TMX_STAMPS_BUFFER"))
+    if (env[0] == '1' && a->partial_ml != nullptr) p.stamps = reinterpret_cast<unsigned long long*>(a->partial_ml + (1 << 19));
 #endif
   const int64_t lim = 0x7FFFFFFF;
   TMX_CHECK_SUPPORTED(a->q_stride_t <= lim && a->q_stride_h <= lim && a->out_stride_t <= lim &&
