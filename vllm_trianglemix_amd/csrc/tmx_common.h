@@ -64,24 +64,28 @@ struct TileRanges {
   TMX_HD bool contains(int t) const { return (t >= a0 && t <= a1) || (t >= b0 && t <= b1); }
 };
 
-TMX_HD TileRanges tile_ranges(int mode, int i_min, int i_max, int n, int n_full, int si, int sl, int last, int bn) {
+// bn_shift: log2(bn) when bn is a power of two (every quotient below then is a shift of a non-negative
+// number: a general integer division costs the GPU some forty instructions), -1 otherwise.
+TMX_HD TileRanges tile_ranges(int mode, int i_min, int i_max, int n, int n_full, int si, int sl, int last, int bn,
+                              int bn_shift = -1) {
   TileRanges r{0, -1, 0, -1};
-  const int nt = ceil_div(n, bn);
+  auto tile_of = [&](int key) { return bn_shift >= 0 ? key >> bn_shift : key / bn; };  // key >= 0
+  const int nt = n > 0 ? tile_of(n - 1) + 1 : 0;
   if (nt <= 0 || i_max < i_min) return r;
   if (mode == TMX_MODE_NONE) {
     r.a1 = nt - 1;
     return r;
   }
-  const int t_diag = i_max / bn;
+  const int t_diag = tile_of(i_max);
   if (mode == TMX_MODE_CAUSAL || (n_full - i_max) < last) {
     r.a1 = t_diag;
     return r;
   }
   const int a_hi = imin(i_max, si);
   const bool has_sink = a_hi >= 0;
-  if (has_sink) r.a1 = a_hi / bn;
+  if (has_sink) r.a1 = tile_of(a_hi);
   if (sl >= 0) {
-    const int b_lo = imax(0, i_min - sl) / bn;
+    const int b_lo = tile_of(imax(0, i_min - sl));
     if (has_sink && b_lo <= r.a1 + 1) {
       r.a1 = imax(r.a1, t_diag);
     } else if (has_sink) {

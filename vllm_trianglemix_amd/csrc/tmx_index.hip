@@ -75,6 +75,7 @@ struct IndexParams {
   int batch, block_m, block_n, mode, chunk, si, sl, last, tri_min_len;
   int cap_qblocks, cap_nnz, cap_items, cap_split;
   int fused;  // pass 2 inside the scan launch (host: cap_qblocks <= 1024)
+  int bn_shift, bm_shift;  // log2 of block_n / block_m when powers of two, else -1
 };
 
 // Position of a q-block's first work item.  The list starts with the pieces of all split q-blocks (the
@@ -125,7 +126,7 @@ __device__ __forceinline__ void fill_qblock(const IndexParams& p, int qb, int b,
       }
   }
   // work items: pieces of one q-block ascending from first_item
-  const int pieces = imax(1, ceil_div(cnt, p.chunk));
+  const int pieces = cnt <= p.chunk ? 1 : ceil_div(cnt, p.chunk);
   for (int pc = e0; pc < pieces; pc += estep) {
     const int it = first_item + pc;
     if (it < p.cap_items) {
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
     int nqb = 0;
     if (b < p.batch) {
       const int q0 = p.cu_q[b], q1 = p.cu_q[b + 1];
-      nqb = ceil_div(imax(0, q1 - q0), p.block_m);
+      const int rows = imax(0, q1 - q0);
+      nqb = p.bm_shift >= 0 ? (rows + p.block_m - 1) >> p.bm_shift : ceil_div(rows, p.block_m);
       if (cached) {
         const int n = p.seq_lens[b];
         s_req[b] = make_int4(q0, q1 - q0, n, p.full_lens ? imax(n, p.full_lens[b]) : n);
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
     const int qb = base + tid;
     Int4 v{0, 0, 0, 0};
     int b = 0, r0 = 0;
+    TileRanges tr_own{0, -1, 0, -1};  // this thread's q-block (kept for pass 2)
     if (qb < R) {
       int lo = 0, hi = p.batch;  // last b with seq_qb_ptr[b] <= qb
       while (hi - lo > 1) {
@@ -214,8 +217,9 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
       const int ql = rq.y, n = rq.z, nf = rq.w;
       const int ctx = n - ql;
       const int r1 = imin(r0 + p.block_m, ql);
-      const int cnt = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si, p.sl, p.last, p.block_n).count();
-      const int pieces = imax(1, ceil_div(cnt, p.chunk));
+      tr_own = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si, p.sl, p.last, p.block_n, p.bn_shift);
+      const int cnt = tr_own.count();
+      const int pieces = cnt <= p.chunk ? 1 : ceil_div(cnt, p.chunk);
       v = Int4{cnt, pieces, pieces > 1 ? pieces : 0, pieces > 1 ? 1 : 0};
       max_tiles = imax(max_tiles, cnt);
     }
@@ -236,14 +240,11 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
       bool is_long = false;
       if (qb < R && qb < p.cap_qblocks) {
         const int4 rq = request(b);
-        const int ql = rq.y, n = rq.z, nf = rq.w;
+        const int ql = rq.y, n = rq.z;
         const int ctx = n - ql;
-        const int r1 = imin(r0 + p.block_m, ql);
-        const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si,
-                                          p.sl, p.last, p.block_n);
         is_long = v.x > kLongList;
         if (!is_long)
-          fill_qblock(p, qb, b, r0, n, ctx, rq.x + r0, tr, v.x, e.x, first_item_of(run.y, run.z, e.y, e.z, v.y), e.z, 0, 1);
+          fill_qblock(p, qb, b, r0, n, ctx, rq.x + r0, tr_own, v.x, e.x, first_item_of(run.y, run.z, e.y, e.z, v.y), e.z, 0, 1);
       }
       if (is_long) {
         const int at = atomicAdd(&s_num_long, 1);
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
         const int ctx = n - ql;
         const int r1 = imin(lr0 + p.block_m, ql);
         const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + lr0, ctx + r1 - 1, n, nf, p.si,
-                                          p.sl, p.last, p.block_n);
+                                          p.sl, p.last, p.block_n, p.bn_shift);
         const int cnt = tr.count();
         const int pieces = imax(1, ceil_div(cnt, p.chunk));
         fill_qblock(p, lq, lb, lr0, n, ctx, rq.x + lr0, tr, cnt, s_long[k][3],
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
             const int ctx = n - ql;
             const int r1 = imin(r0 + p.block_m, ql);
             const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf,
-                                              p.si, p.sl, p.last, p.block_n);
+                                              p.si, p.sl, p.last, p.block_n, p.bn_shift);
             fill_qblock(p, qb, b, r0, n, ctx, rq.x + r0, tr, v.x, e.x, first_item_of(run.y, run.z, e.y, e.z, v.y), e.z, 0, 1);
           }
         }
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IndexParams p) {
   const int nf = p.full_lens ? imax(n, p.full_lens[b]) : n;
   const int ctx = n - ql;
   const int r1 = imin(r0 + p.block_m, ql);
-  const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si, p.sl, p.last, p.block_n);
+  const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si, p.sl, p.last, p.block_n, p.bn_shift);
   const int cnt = tr.count();
   const int pieces = imax(1, ceil_div(cnt, p.chunk));
   fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, cnt, p.row_ptr[qb],
@@ -409,6 +410,8 @@ extern "C" int tmx_build_block_index(tmx_index_t* idx, const int32_t* cu_q_dev, 
   p.cap_items = (int)idx->cap_items;
   p.cap_split = (int)idx->cap_split;
   p.fused = idx->cap_qblocks <= 1024 ? 1 : 0;
+  p.bn_shift = (idx->block_n & (idx->block_n - 1)) == 0 ? __builtin_ctz(idx->block_n) : -1;
+  p.bm_shift = (idx->block_m & (idx->block_m - 1)) == 0 ? __builtin_ctz(idx->block_m) : -1;
   hipStream_t s = (hipStream_t)stream;
   tmx::index_scan_kernel<<<1, 1024, 0, s>>>(p);
   TMX_CHECK_HIP(hipGetLastError());
