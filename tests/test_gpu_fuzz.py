@@ -61,6 +61,12 @@ def test_random_steps_match_the_oracle(seed):
     paged = rng.random() < 0.7
     page = int(rng.choice([16, 32, 64]))
     fused = paged and mode != "none" and rng.random() < 0.5  # the launch stores the step's rows itself
+    fp8 = paged and not fused and D == 128 and rng.random() < 0.35  # an fp8 (e4m3fn) cache read in place
+    k_scale, v_scale = ((1.0, 1.0) if rng.random() < 0.5 else (0.75, 1.5)) if fp8 else (1.0, 1.0)
+    # chunked prefill: some requests are chunks of a longer prompt (the pattern then refers to the whole prompt)
+    full_lens = None
+    if mode == "triangle" and rng.random() < 0.4:
+        full_lens = [n + (int(rng.integers(0, 500)) if q < n and rng.random() < 0.7 else 0) for q, n in zip(q_lens, seq_lens)]
     flags = 0
     if max(q_lens) <= 16 and rng.random() < 0.5:
         flags |= TMX_ATTN_SHORT_QUERIES
@@ -81,11 +87,15 @@ def test_random_steps_match_the_oracle(seed):
     bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
     scale = D ** -0.5
     desc = dict(seed=seed, q=q_lens, n=seq_lens, heads=(H, Hkv, D), dtype=str(dtype), mode=mode, pat=pat, gate=gate,
-                chunk=chunk, paged=paged, page=page, fused=fused, flags=flags)
+                chunk=chunk, paged=paged, page=page, fused=fused, flags=flags, fp8=fp8, scales=(k_scale, v_scale),
+                full_lens=full_lens)
+    fl_h = None if full_lens is None else np.asarray(full_lens, np.int32)
+    fl_d = None if full_lens is None else torch.from_numpy(fl_h).to(DEV)
+    k_ref, v_ref = ks, vs
     if paged:
         nblk = sum((n + page - 1) // page for n in seq_lens) + 2
         perm = rng.permutation(nblk).astype(np.int32)
-        kc = torch.zeros((nblk, page, Hkv, D), dtype=dtype, device=DEV)
+        kc = torch.zeros((nblk, page, Hkv, D), dtype=torch.uint8 if fp8 else dtype, device=DEV)
         vc = torch.zeros_like(kc)
         bt = np.zeros((B, max((n + page - 1) // page for n in seq_lens)), np.int32)
         nxt, new_slots, k_new, v_new = 0, [], [], []
@@ -97,7 +107,10 @@ def test_random_steps_match_the_oracle(seed):
             slots = bt[b, pos // page].astype(np.int64) * page + pos % page
             ctx = n - q_lens[b]
             old = slice(0, ctx) if fused else slice(0, n)  # with the fused write only the context is in the cache yet
-            if old.stop > 0:
+            if old.stop > 0 and fp8:
+                ops.reshape_and_cache_fp8(to_dev(ks[b][old]), to_dev(vs[b][old]), kc, vc, torch.from_numpy(slots[old]).to(DEV),
+                                          k_scale, v_scale)
+            elif old.stop > 0:
                 ops.reshape_and_cache(to_dev(ks[b][old]), to_dev(vs[b][old]), kc, vc, torch.from_numpy(slots[old]).to(DEV))
             new_slots.append(slots[ctx:])
             k_new.append(ks[b][ctx:])
@@ -105,7 +118,8 @@ def test_random_steps_match_the_oracle(seed):
         btd = torch.from_numpy(bt).to(DEV)
         resolve = rng.random() < 0.5
         idx = ops.build_block_index(cu, sld, cu_h, sl_h, *pat, bm, bn, ops.MODES[mode], chunk_tiles=chunk, tri_min_len=gate,
-                                    block_table=btd if resolve else None, page_size=page if resolve else 0)
+                                    block_table=btd if resolve else None, page_size=page if resolve else 0,
+                                    full_lens=fl_d, full_lens_cpu=fl_h)
         if fused:
             kn, vn = to_dev(np.concatenate(k_new, 0)), to_dev(np.concatenate(v_new, 0))
             slots_d = torch.from_numpy(np.concatenate(new_slots)).to(DEV)
@@ -114,16 +128,24 @@ def test_random_steps_match_the_oracle(seed):
             # the cache now holds every row of every request
             kf, vf = kc.view(nblk * page, Hkv, D), vc.view(nblk * page, Hkv, D)
             assert torch.equal(kf[slots_d], kn) and torch.equal(vf[slots_d], vn), desc
+        elif fp8:
+            ops.attention(qd, kc.view(torch.float8_e4m3fn), vc.view(torch.float8_e4m3fn), out, idx, cu, sld, scale,
+                          block_table=btd, flags=flags, k_scale=k_scale, v_scale=v_scale)
+            # the oracle attends to what the cache holds: fp8(x / scale) x scale, rounded once to the 16-bit type
+            seen = lambda x, sc: _round(orc.fp8_cache_roundtrip(x, sc).astype(np.float32), dtype)  # noqa: E731
+            k_ref, v_ref = [seen(k, k_scale) for k in ks], [seen(v, v_scale) for v in vs]
         else:
             ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, flags=flags)
     else:
-        idx = ops.build_block_index(cu, sld, cu_h, sl_h, *pat, bm, bn, ops.MODES[mode], chunk_tiles=chunk, tri_min_len=gate)
+        idx = ops.build_block_index(cu, sld, cu_h, sl_h, *pat, bm, bn, ops.MODES[mode], chunk_tiles=chunk, tri_min_len=gate,
+                                    full_lens=fl_d, full_lens_cpu=fl_h)
         cu_k = torch.from_numpy(np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)).to(DEV)
         ops.attention(qd, to_dev(np.concatenate(ks, 0)), to_dev(np.concatenate(vs, 0)), out, idx, cu, sld, scale,
                       cu_seqlens_k=cu_k, flags=flags)
     torch.cuda.synchronize()
     got = out.cpu().numpy()
-    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu_h, seq_lens, scale, mode, *pat, tri_min_len=gate)
+    ref = orc.varlen_gqa_attention(q, lambda b: k_ref[b], lambda b: v_ref[b], cu_h, seq_lens, scale, mode, *pat,
+                                   full_lens=full_lens, tri_min_len=gate)
     # rows the pattern leaves without any key (a window of 0 keys and no sink, say) are NaN in both
     both_nan = np.isnan(got) & np.isnan(ref)
     assert np.array_equal(np.isnan(got), np.isnan(ref)), desc
