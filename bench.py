@@ -373,7 +373,8 @@ def main():
     # passes (FETCH_SIZE x 2 + WRITE_SIZE; tools/profile_round.sh writes the file); null when absent
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and world == 1:
+    # (the counters were taken on the default workload: one 32k prompt, Qwen3-8B heads, 16-bit cache)
+    if os.path.exists(tpath) and world == 1 and job_world == 1 and args.model == "8b" and batch == 1 and not fp8:
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("seq_len") == n and tj.get("kernel") == "attn_kernel":

@@ -8,7 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_trianglemix_amd import ops
 from vllm_trianglemix_amd._lib import TMX_ATTN_DECODE_ONLY, TMX_ATTN_NO_DECODE, TMX_ATTN_SHORT_QUERIES
 
-H, Hkv, D, PAGE = 32, 8, 128, 16
+H, Hkv = (int(x) for x in os.environ.get("HEADS", "32,8").split(","))   # query heads, K/V heads
+D, PAGE = 128, 16
 dev = torch.device("cuda:0")
 shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(64, 8192), (8, 32768), (256, 2048), (1, 131072)]
 chunks = [int(x) for x in os.environ.get("CHUNKS", "0").split(",")]   # 0: the library's advice

@@ -1882,7 +1882,8 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.decode_on = 0;
   uint32_t flags = a->flags;
   {
-    const int Yd = a->num_kv_heads * (G / 4 > 0 ? G / 4 : 1);
+    const int hw_d = G % 8 == 0 ? 8 : 4;  // query heads per decode workgroup (all of them share the K/V loads)
+    const int Yd = a->num_kv_heads * (G / hw_d > 0 ? G / hw_d : 1);
     const bool shape_ok = !has_bias && G % 4 == 0 && a->head_dim == 128 && (!paged || a->page_size >= 16) &&
                           (a->mode != TMX_MODE_TRIANGLE || a->last >= 2) &&
                           !(a->flags & (TMX_ATTN_NO_DECODE | TMX_ATTN_ONLY_COMBINE));
@@ -1922,6 +1923,7 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
       d.H = p.H;
       d.Hkv = p.Hkv;
       d.G = G;
+      d.hw = hw_d;
       d.Y = Yd;
       d.block_m = p.block_m;
       d.num_items = p.num_items;

@@ -4,7 +4,8 @@
 // of its K/V once and does almost no arithmetic: the work-list kernel's LDS ring, barriers and 16-row tiles
 // buy nothing there.  This kernel streams K/V straight from memory into registers:
 //
-//   workgroup = 4 waves = one work item (a piece of a request's key range) x 4 query heads of one K/V head;
+//   workgroup = 4 waves = one work item (a piece of a request's key range) x 4 query heads of one K/V head (8
+//   when the group size is a multiple of 8: the K/V of a head are then still read once);
 //   the waves take the piece's 32-key tiles in turn and never synchronise until the end.
 //   Per 16 keys and wave: K rows arrive in the A layout of v_mfma_f32_16x16x32 (lane = key, 16 bytes of the
 //   row per k-step), the 4 query heads are 4 of the 16 B columns, so 4 matrix instructions give all scores;
@@ -73,12 +74,13 @@ __device__ __forceinline__ void dc_unpack(uint32_t w, float& lo, float& hi) {
   }
 }
 
-template <bool BF16, bool PAGED, bool KV8, bool UNIT>
+template <bool BF16, bool PAGED, bool KV8, bool UNIT, int HW>
 __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
   constexpr int D = 128;
   constexpr int KVB = KV8 ? 1 : 2;
-  __shared__ float part_o[16][4][D];   // [wave * 4 + lane group][head][column]
-  __shared__ float part_ml[16][4][2];
+  static_assert(HW == 4 || HW == 8, "4 or 8 query heads per workgroup");
+  __shared__ float part_o[16][HW][D];   // [wave * 4 + lane group][head][column]
+  __shared__ float part_ml[16][HW][2];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -123,9 +125,9 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
   }
   const int ntiles = a0.z, slot = a0.w;
   const int tile0 = ntiles > 0 ? dcs(p.col_idx + a0.y) : 0;  // a dense row's tiles are consecutive
-  const int chunks = p.G / 4;
+  const int chunks = p.G / HW;
   const int kvh = kvc / chunks;
-  const int head0 = kvh * p.G + (kvc - kvh * chunks) * 4;
+  const int head0 = kvh * p.G + (kvc - kvh * chunks) * HW;
   const int key_end = imin(n, pos + 1);  // keys 0 .. key_end - 1 are attended (all n of them when nothing is masked)
   const int n_att = p.mode == TMX_MODE_NONE ? n : key_end;
 
@@ -134,12 +136,12 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
   // columns) at a time, whose halves feed k-steps 2 j and 2 j + 1: those cover columns 64 j + 16 g + 8 h .. ----
   uint4 qf[4];
   {
-    const char* qrow = reinterpret_cast<const char*>(p.q) + 2ll * ((long long)q_tok * p.q_stride_t + (long long)(head0 + (c16 & 3)) * p.q_stride_h);
+    const char* qrow = reinterpret_cast<const char*>(p.q) + 2ll * ((long long)q_tok * p.q_stride_t + (long long)(head0 + (c16 & (HW - 1))) * p.q_stride_h);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int col = KV8 ? 64 * (ks >> 1) + 16 * g + 8 * (ks & 1) : 32 * ks + 8 * g;
       qf[ks] = *reinterpret_cast<const uint4*>(qrow + 2 * col);
-      if (c16 >= 4) qf[ks] = make_uint4(0, 0, 0, 0);
+      if (c16 >= HW) qf[ks] = make_uint4(0, 0, 0, 0);
     }
   }
 
@@ -200,15 +202,15 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
     for (int i = 0; i < 4; ++i) r.v[i] = *reinterpret_cast<const VRaw*>(row_ptr(vbase, p.v_new, jb + 4 * g + i) + KVB * 8 * c16);
   };
 
-  float m_run = kDcMinusBig, l_run = 0.f;  // of head c16 over the keys of lane group g (lanes c16 < 4)
-  float o[4][8];                            // of the 4 heads, columns 8 c16 .. + 7, over the keys of lane group g
+  float m_run = kDcMinusBig, l_run = 0.f;  // of head c16 over the keys of lane group g (lanes c16 < HW)
+  float o[HW][8];                           // of the HW heads, columns 8 c16 .. + 7, over the keys of lane group g
 #pragma unroll
-  for (int hh = 0; hh < 4; ++hh)
+  for (int hh = 0; hh < HW; ++hh)
 #pragma unroll
     for (int x = 0; x < 8; ++x) o[hh][x] = 0.f;
-  int src_lane[4];  // ds_bpermute byte address of lane (head hh, group g)
+  int src_lane[HW];  // ds_bpermute byte address of lane (head hh, group g)
 #pragma unroll
-  for (int hh = 0; hh < 4; ++hh) src_lane[hh] = 4 * (16 * g + hh);
+  for (int hh = 0; hh < HW; ++hh) src_lane[hh] = 4 * (16 * g + hh);
 
   // 8 fp8 values (two dwords) as 8 values of the 16-bit type: value = fp8 x scale rounded once; a unit scale
   // converts exactly (every e4m3 value is a bf16 and an fp16 value)
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
     }
     if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-      for (int hh = 0; hh < 4; ++hh) {
+      for (int hh = 0; hh < HW; ++hh) {
         const float ah = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane[hh], __float_as_int(alpha)));
 #pragma unroll
         for (int x = 0; x < 8; ++x) o[hh][x] *= ah;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
         dc_unpack<BF16>(r.v[i].w, vf[6], vf[7]);
       }
 #pragma unroll
-      for (int hh = 0; hh < 4; ++hh) {
+      for (int hh = 0; hh < HW; ++hh) {
         const float ph = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane[hh], __float_as_int(pr[i])));
 #pragma unroll
         for (int x = 0; x < 8; ++x) o[hh][x] = __builtin_fmaf(ph, vf[x], o[hh][x]);
@@ -339,17 +341,17 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
 
   // ---- merge the 16 partial results of the workgroup ----
   const int pi = wave * 4 + g;
-  if (c16 < 4) {
+  if (c16 < HW) {
     part_ml[pi][c16][0] = m_run;
     part_ml[pi][c16][1] = l_run;
   }
 #pragma unroll
-  for (int hh = 0; hh < 4; ++hh)
+  for (int hh = 0; hh < HW; ++hh)
 #pragma unroll
     for (int x = 0; x < 8; ++x) part_o[pi][hh][8 * c16 + x] = o[hh][x];
   __syncthreads();
-  {
-    const int hh = tid >> 6;           // head of this thread
+#pragma unroll
+  for (int hh = tid >> 6; hh < HW; hh += 4) {  // head(s) of this thread
     const int d0 = 2 * (tid & 63);     // its two columns
     float M = kDcMinusBig;
 #pragma unroll
@@ -383,22 +385,29 @@ int launch_decode(const DecodeParams& p, bool bf16, bool paged, hipStream_t s) {
   if (grid <= 0) return TMX_OK;
   TMX_CHECK_SUPPORTED(grid < (1ll << 31), "decode kernel: too many work items");
   const unsigned gsz = (unsigned)grid;
+  // (instantiations: cache type x scales x heads per workgroup)
+#define TMX_DECODE_LAUNCH(BF, PG, K8, UN)                                             \
+  do {                                                                               \
+    if (p.hw == 8) decode_kernel<BF, PG, K8, UN, 8><<<gsz, 256, 0, s>>>(p);          \
+    else decode_kernel<BF, PG, K8, UN, 4><<<gsz, 256, 0, s>>>(p);                    \
+  } while (0)
   if (p.kv_fp8) {
     const bool unit = p.k_scale == 1.0f && p.v_scale == 1.0f;
     if (unit) {
-      if (bf16) decode_kernel<true, true, true, true><<<gsz, 256, 0, s>>>(p);
-      else decode_kernel<false, true, true, true><<<gsz, 256, 0, s>>>(p);
+      if (bf16) TMX_DECODE_LAUNCH(true, true, true, true);
+      else TMX_DECODE_LAUNCH(false, true, true, true);
     } else {
-      if (bf16) decode_kernel<true, true, true, false><<<gsz, 256, 0, s>>>(p);
-      else decode_kernel<false, true, true, false><<<gsz, 256, 0, s>>>(p);
+      if (bf16) TMX_DECODE_LAUNCH(true, true, true, false);
+      else TMX_DECODE_LAUNCH(false, true, true, false);
     }
   } else if (bf16) {
-    if (paged) decode_kernel<true, true, false, false><<<gsz, 256, 0, s>>>(p);
-    else decode_kernel<true, false, false, false><<<gsz, 256, 0, s>>>(p);
+    if (paged) TMX_DECODE_LAUNCH(true, true, false, false);
+    else TMX_DECODE_LAUNCH(true, false, false, false);
   } else {
-    if (paged) decode_kernel<false, true, false, false><<<gsz, 256, 0, s>>>(p);
-    else decode_kernel<false, false, false, false><<<gsz, 256, 0, s>>>(p);
+    if (paged) TMX_DECODE_LAUNCH(false, true, false, false);
+    else TMX_DECODE_LAUNCH(false, false, false, false);
   }
+#undef TMX_DECODE_LAUNCH
   TMX_CHECK_HIP(hipGetLastError());
   return TMX_OK;
 }
