@@ -296,6 +296,9 @@ typedef struct tmx_attention_args_t {
  * (head size 128, no bias, a causal or unmasked launch or a pattern with last >= 2 and no full_lens).  A step
  * that sets it with a longer request in the batch leaves that request's rows unwritten. */
 #define TMX_ATTN_DECODE_ONLY 64u
+/* Measurement aid: the decode kernel forms its weighted sum on the vector units instead of the matrix cores
+ * (its first implementation; same results within the tolerance of the attention). */
+#define TMX_ATTN_DECODE_VALU 128u
 
 int tmx_attention(const tmx_attention_args_t* args, void* stream);
 

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import trianglemix_oracle as orc
-from vllm_trianglemix_amd._lib import (TMX_ATTN_NO_BAND, TMX_ATTN_NO_DECODE, TMX_ATTN_NO_DENSE,
+from vllm_trianglemix_amd._lib import (TMX_ATTN_DECODE_VALU, TMX_ATTN_NO_BAND, TMX_ATTN_NO_DECODE, TMX_ATTN_NO_DENSE,
                                        TMX_ATTN_SHORT_QUERIES)
 
 pytestmark = pytest.mark.gpu
@@ -70,7 +70,7 @@ def test_random_steps_match_the_oracle(seed):
     flags = 0
     if max(q_lens) <= 16 and rng.random() < 0.5:
         flags |= TMX_ATTN_SHORT_QUERIES
-    for f in (TMX_ATTN_NO_BAND, TMX_ATTN_NO_DENSE, TMX_ATTN_NO_DECODE):
+    for f in (TMX_ATTN_NO_BAND, TMX_ATTN_NO_DENSE, TMX_ATTN_NO_DECODE, TMX_ATTN_DECODE_VALU):
         if rng.random() < 0.25:
             flags |= f
 

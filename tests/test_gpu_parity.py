@@ -1244,7 +1244,7 @@ def test_decode_kernel_matches_oracle_and_work_list(case):
     end, pieces of long rows through the partial slots.  Same results as the oracle and as the same launch
     kept on the work list (TMX_ATTN_NO_DECODE); lengths around the 16-key groups, the 32-key tiles and the
     pieces' ends; with and without the caller's all-decode hint."""
-    from vllm_trianglemix_amd._lib import TMX_ATTN_DECODE_ONLY, TMX_ATTN_NO_DECODE
+    from vllm_trianglemix_amd._lib import TMX_ATTN_DECODE_ONLY, TMX_ATTN_DECODE_VALU, TMX_ATTN_NO_DECODE
     ops = _ops()
     H, Hkv, D = case["H"], case["Hkv"], 128
     seq_lens = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 700, 1023, 2049, 3000, 4100]
@@ -1268,7 +1268,8 @@ def test_decode_kernel_matches_oracle_and_work_list(case):
     cu = np.concatenate([[0], np.cumsum(q_lens)])
     ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu, seq_lens, scale, mode, *pat, tri_min_len=gate)
     tol = ATOL_F32_OUT + (np.abs(ref) * 2.0 ** -8 if out_dtype != torch.float32 else 0.0)
-    variants = [("decode kernel", 0), ("work list", TMX_ATTN_NO_DECODE)]
+    variants = [("decode kernel", 0), ("decode kernel, sum on the vector units", TMX_ATTN_DECODE_VALU),
+                ("work list", TMX_ATTN_NO_DECODE)]
     if not case.get("mixed"):
         variants.append(("decode kernel alone", TMX_ATTN_DECODE_ONLY))
     for name, flags in variants:
@@ -1285,7 +1286,7 @@ def test_decode_kernel_fp8_cache(dtype, scales):
     """Decode rows out of an fp8 (e4m3fn) cache: the decode kernel converts in registers (unit scales: the
     exact conversion instruction; other scales: value = fp8 x scale rounded once to the 16-bit type).  Checked
     against the oracle on the dequantised values and against the work-list kernel's conversion stage."""
-    from vllm_trianglemix_amd._lib import TMX_ATTN_DECODE_ONLY, TMX_ATTN_NO_DECODE
+    from vllm_trianglemix_amd._lib import TMX_ATTN_DECODE_ONLY, TMX_ATTN_DECODE_VALU, TMX_ATTN_NO_DECODE
     ops = _ops()
     H, Hkv, D, page = 16, 2, 128, 16
     k_scale, v_scale = scales
@@ -1318,7 +1319,8 @@ def test_decode_kernel_fp8_cache(dtype, scales):
                                    4, 32, 64)
     idx, cu, sld = _build(ops, q_lens, seq_lens, 4, 32, 64, ops.attention_block_m(H, Hkv), 32, ops.MODES["triangle"], 16,
                           block_table=btd, page_size=page)
-    for name, flags in (("decode kernel", 0), ("decode kernel alone", TMX_ATTN_DECODE_ONLY), ("work list", TMX_ATTN_NO_DECODE)):
+    for name, flags in (("decode kernel", 0), ("decode kernel alone", TMX_ATTN_DECODE_ONLY),
+                        ("decode kernel, sum on the vector units", TMX_ATTN_DECODE_VALU), ("work list", TMX_ATTN_NO_DECODE)):
         out = torch.full((B, H, D), float("nan"), dtype=torch.float32, device=DEV)
         ops.attention(_to_dev(q, dtype), kc.view(torch.float8_e4m3fn), vc.view(torch.float8_e4m3fn), out, idx, cu, sld,
                       scale, block_table=btd, flags=flags, k_scale=k_scale, v_scale=v_scale)

@@ -74,7 +74,7 @@ class AttentionArgs(Structure):
     ]
 
 TMX_ATTN_SKIP_COMBINE, TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES, TMX_ATTN_NO_BAND, TMX_ATTN_NO_DENSE = 1, 2, 4, 8, 16
-TMX_ATTN_NO_DECODE, TMX_ATTN_DECODE_ONLY = 32, 64
+TMX_ATTN_NO_DECODE, TMX_ATTN_DECODE_ONLY, TMX_ATTN_DECODE_VALU = 32, 64, 128
 
 
 _lib = None

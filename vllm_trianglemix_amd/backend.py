@@ -98,20 +98,24 @@ class TriangleMixAttentionMetadata:
     _workspaces: Dict[Tuple, tuple] = field(default_factory=dict, repr=False)
 
     def block_index(self, mode: str, pattern: Tuple[int, int, int], num_heads: int, num_kv_heads: int,
-                    tri_min_len: int) -> "ops.BlockIndex":
+                    tri_min_len: int, fp8_cache: bool = False) -> "ops.BlockIndex":
         """The step's index for (mode, pattern, head grouping): built on first use, then
         shared by every layer that asks for the same one (the mask does not depend on the layer
         beyond the triangle/dense choice)."""
         block_m = ops.attention_block_m(num_heads, num_kv_heads)
-        key = (mode, pattern, block_m, tri_min_len)
+        # a step of one-row requests out of an fp8 cache is cut for the decode kernel's workgroups (8 query heads
+        # each when the group size allows): half the bytes per key, so twice the pieces keep the chip busy
+        units = ops.units_per_item(num_heads, num_kv_heads)
+        if fp8_cache and self.max_query_len == 1:
+            units = ops.decode_units_per_item(num_heads, num_kv_heads)
+        key = (mode, pattern, block_m, tri_min_len, units)
         idx = self._indices.get(key)
         if idx is None:
             # piece length for this batch and head grouping: one piece of the dense rows per CU when the step
             # also holds sparse rows, 128-tile pieces for pure decode steps (tmx_suggest_chunk_tiles)
             chunk = ops.suggest_chunk_tiles(self.query_start_loc_cpu, self.seq_lens_cpu, pattern[0], pattern[1],
                                             pattern[2], block_m, ops.attention_block_n(), ops.MODES[mode],
-                                            ops.units_per_item(num_heads, num_kv_heads), tri_min_len=tri_min_len,
-                                            full_lens_cpu=self.prompt_lens_cpu)
+                                            units, tri_min_len=tri_min_len, full_lens_cpu=self.prompt_lens_cpu)
             idx = ops.build_block_index(self.query_start_loc, self.seq_lens, self.query_start_loc_cpu,
                                         self.seq_lens_cpu, pattern[0], pattern[1], pattern[2], block_m,
                                         ops.attention_block_n(), ops.MODES[mode], chunk_tiles=chunk,
@@ -403,7 +407,7 @@ class TriangleMixAttentionImpl(_ImplBase):
         mode = "triangle" if self.use_triangle else "causal"
         pattern = self.pattern if self.use_triangle else (0, 0, 0)
         tri_min_len = self.tri_min_len if self.use_triangle else 0
-        idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len)
+        idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len, fp8_cache=self.head_size == 128)
         ws = m.workspace(idx, self.num_heads, self.head_size, q.device)
         if self.head_size == 128:
             # the attention kernel reads the fp8 pages in place and descales inside its tile loop

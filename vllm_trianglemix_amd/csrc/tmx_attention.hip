@@ -1924,6 +1924,7 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
       d.Hkv = p.Hkv;
       d.G = G;
       d.hw = hw_d;
+      d.valu_sum = (a->flags & TMX_ATTN_DECODE_VALU) ? 1 : 0;
       d.Y = Yd;
       d.block_m = p.block_m;
       d.num_items = p.num_items;

@@ -44,6 +44,7 @@ struct DecodeParams {
   int kv_stride_page, kv_stride_t, kv_stride_h, block_table_stride;
   int page_size, page_shift;  // a power of two, at least 16
   int H, Hkv, G;              // G = H / Hkv, a multiple of 4
+  int valu_sum;               // weighted sum on the vector units instead of the matrix cores (TMX_ATTN_DECODE_VALU)
   int hw;                     // query heads per workgroup: 8 when G is a multiple of 8, else 4
   int Y;                      // K/V head chunks: Hkv * G / hw
   int block_m;                // rows per q-block of the index (layout of the partial slots)

@@ -28,6 +28,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 dc_bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 dc_f16x8;
 typedef __attribute__((ext_vector_type(4))) int dc_i32x4;
 typedef __attribute__((ext_vector_type(2))) float dc_f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned dc_u32x4;
+typedef __attribute__((ext_vector_type(4))) short dc_s16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 dc_f16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 dc_bf16x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 dc_f16x2;
 
@@ -74,13 +77,16 @@ __device__ __forceinline__ void dc_unpack(uint32_t w, float& lo, float& hi) {
   }
 }
 
-template <bool BF16, bool PAGED, bool KV8, bool UNIT, int HW>
+template <bool BF16, bool PAGED, bool KV8, bool UNIT, int HW, bool MPV>
 __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
   constexpr int D = 128;
   constexpr int KVB = KV8 ? 1 : 2;
   static_assert(HW == 4 || HW == 8, "4 or 8 query heads per workgroup");
-  __shared__ float part_o[16][HW][D];   // [wave * 4 + lane group][head][column]
-  __shared__ float part_ml[16][HW][2];
+  // MPV: the weighted sum runs on the matrix cores too (V through a 4-KiB LDS stage of the wave's own, read
+  // back transposed); the accumulators then hold a wave's sum over all its keys
+  __shared__ float part_o[MPV ? 4 : 16][HW][D];   // [wave (* 4 + lane group)][head][column]
+  __shared__ float part_ml[16][HW][2];             // [wave * 4 + lane group][head][(max, sum)]
+  __shared__ __attribute__((aligned(1024))) char v_stage[MPV ? 4 * 4096 : 16];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -211,10 +217,26 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
   int src_lane[HW];  // ds_bpermute byte address of lane (head hh, group g)
 #pragma unroll
   for (int hh = 0; hh < HW; ++hh) src_lane[hh] = 4 * (16 * g + hh);
+  // MPV: O^T[column][head]: register c of acc[db] is column 16 db + 4 g + c of head c16, summed over all keys
+  dc_f32x4 acc[8];
+#pragma unroll
+  for (int db = 0; db < 8; ++db) acc[db] = dc_f32x4{0.f, 0.f, 0.f, 0.f};
+  // the wave's V stage: 16 key rows of 256 bytes, 32-byte chunks XOR-swizzled by the row (rows 0..7 of a
+  // transposed read then hit different banks).  Write side: this lane's 16 bytes of key row 4 g + i; read side
+  // (ds_read_b64_tr_b16): lane 4 q + pp of a 16-lane group addresses key row 4 g + q, columns 16 db + 4 pp ..
+  const unsigned vst = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)v_stage) + (MPV ? 4096u * wave : 0u);
+  unsigned vst_w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * g + i;
+    vst_w[i] = vst + row * 256 + 32 * ((c16 >> 1) ^ (row & 7)) + 16 * (c16 & 1);
+  }
+  const int tr_row = 4 * g + (c16 >> 2);
+  const unsigned vst_r = vst + tr_row * 256 + 8 * (c16 & 3);
 
   // 8 fp8 values (two dwords) as 8 values of the 16-bit type: value = fp8 x scale rounded once; a unit scale
   // converts exactly (every e4m3 value is a bf16 and an fp16 value)
-  auto k_from_fp8 = [&](uint32_t w0, uint32_t w1) -> uint4 {
+  auto k_from_fp8 = [&](uint32_t w0, uint32_t w1, float scale) -> uint4 {
     if constexpr (UNIT) {
       if constexpr (BF16)
         return make_uint4(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w0, 1.0f, false)),
@@ -229,8 +251,8 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
     } else {
       const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, true);
       const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, true);
-      return make_uint4(dc_pack<BF16>(f0[0] * p.k_scale, f0[1] * p.k_scale), dc_pack<BF16>(f1[0] * p.k_scale, f1[1] * p.k_scale),
-                        dc_pack<BF16>(f2[0] * p.k_scale, f2[1] * p.k_scale), dc_pack<BF16>(f3[0] * p.k_scale, f3[1] * p.k_scale));
+      return make_uint4(dc_pack<BF16>(f0[0] * scale, f0[1] * scale), dc_pack<BF16>(f1[0] * scale, f1[1] * scale),
+                        dc_pack<BF16>(f2[0] * scale, f2[1] * scale), dc_pack<BF16>(f3[0] * scale, f3[1] * scale));
     }
   };
 
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       uint4 kf;
-      if constexpr (KV8) kf = (ks & 1) ? k_from_fp8(r.k[ks >> 1].z, r.k[ks >> 1].w) : k_from_fp8(r.k[ks >> 1].x, r.k[ks >> 1].y);
+      if constexpr (KV8) kf = (ks & 1) ? k_from_fp8(r.k[ks >> 1].z, r.k[ks >> 1].w, p.k_scale) : k_from_fp8(r.k[ks >> 1].x, r.k[ks >> 1].y, p.k_scale);
       else kf = r.k[ks];
       if constexpr (BF16) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dc_bf16x8, kf), __builtin_bit_cast(dc_bf16x8, qf[ks]), s, 0, 0, 0);
       else s = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dc_f16x8, kf), __builtin_bit_cast(dc_f16x8, qf[ks]), s, 0, 0, 0);
@@ -249,7 +271,60 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
     float sc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) sc[c] = (c <= d_hi) ? s[c] * p.scale_log2 : -__builtin_inff();
-    const float tmax = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+    float tmax = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+    if constexpr (MPV) {
+      // the 4 lanes of a head (one per lane group) share one running maximum; it moves only when a group
+      // exceeds it by more than the slack (rare)
+      if (__builtin_amdgcn_ballot_w64(tmax > m_run + kDcSlack) != 0) {
+        const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+        const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+        if (tmax > m_run + kDcSlack) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run - tmax);
+          m_run = tmax;
+          l_run *= alpha;
+#pragma unroll
+          for (int db = 0; db < 8; ++db) acc[db] *= alpha;
+        }
+      }
+      float pr[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pr[c] = __builtin_amdgcn_exp2f(sc[c] - m_run);
+      l_run += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+      // probabilities of keys 4 g .. 4 g + 3 for head c16: the B operand of O^T += V^T P^T as they stand.  bf16 has
+      // 8 significant bits: two terms (truncated high part + rounded rest), fp16 one
+      uint2 p_hi, p_lo = make_uint2(0, 0);
+      if constexpr (BF16) {
+        const uint32_t b0 = __float_as_uint(pr[0]) & 0xffff0000u, b1 = __float_as_uint(pr[1]) & 0xffff0000u;
+        const uint32_t b2 = __float_as_uint(pr[2]) & 0xffff0000u, b3 = __float_as_uint(pr[3]) & 0xffff0000u;
+        p_hi = make_uint2(b1 | (b0 >> 16), b3 | (b2 >> 16));
+        p_lo = make_uint2(dc_pack<true>(pr[0] - __uint_as_float(b0), pr[1] - __uint_as_float(b1)),
+                          dc_pack<true>(pr[2] - __uint_as_float(b2), pr[3] - __uint_as_float(b3)));
+      } else {
+        p_hi = make_uint2(dc_pack<false>(pr[0], pr[1]), dc_pack<false>(pr[2], pr[3]));
+      }
+      // V rows to the stage as 16-bit values (an fp8 cache descaled on the way)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint4 v16;
+        if constexpr (KV8) v16 = k_from_fp8(r.v[i].x, r.v[i].y, p.v_scale);
+        else v16 = r.v[i];
+        *(__attribute__((address_space(3))) dc_u32x4*)(uintptr_t)vst_w[i] = __builtin_bit_cast(dc_u32x4, v16);
+      }
+#pragma unroll
+      for (int db = 0; db < 8; ++db) {
+        const dc_s16x4 vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) dc_s16x4*)(uintptr_t)(vst_r + 32 * (db ^ (tr_row & 7))));
+        if constexpr (BF16) {
+          acc[db] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, __builtin_bit_cast(dc_s16x4, p_hi), acc[db], 0, 0, 0);
+          acc[db] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, __builtin_bit_cast(dc_s16x4, p_lo), acc[db], 0, 0, 0);
+        } else {
+          acc[db] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(dc_f16x4, vf), __builtin_bit_cast(dc_f16x4, p_hi), acc[db], 0, 0, 0);
+        }
+      }
+      return;
+    }
     // the running maximum moves only when a group exceeds it by more than the slack (rare): then the sums of
     // this head in the lanes that hold them (the whole lane group) are rescaled
     float alpha = 1.f;
@@ -345,10 +420,18 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
     part_ml[pi][c16][0] = m_run;
     part_ml[pi][c16][1] = l_run;
   }
+  if constexpr (MPV) {
+    if (c16 < HW) {
 #pragma unroll
-  for (int hh = 0; hh < HW; ++hh)
+      for (int db = 0; db < 8; ++db)
+        *reinterpret_cast<float4*>(&part_o[wave][c16][16 * db + 4 * g]) = make_float4(acc[db][0], acc[db][1], acc[db][2], acc[db][3]);
+    }
+  } else {
 #pragma unroll
-    for (int x = 0; x < 8; ++x) part_o[pi][hh][8 * c16 + x] = o[hh][x];
+    for (int hh = 0; hh < HW; ++hh)
+#pragma unroll
+      for (int x = 0; x < 8; ++x) part_o[pi][hh][8 * c16 + x] = o[hh][x];
+  }
   __syncthreads();
 #pragma unroll
   for (int hh = tid >> 6; hh < HW; hh += 4) {  // head(s) of this thread
@@ -361,8 +444,15 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
     for (int x = 0; x < 16; ++x) {
       const float w = __builtin_amdgcn_exp2f(part_ml[x][hh][0] - M);
       L += w * part_ml[x][hh][1];
-      o0 += w * part_o[x][hh][d0];
-      o1 += w * part_o[x][hh][d0 + 1];
+      if constexpr (MPV) {
+        if ((x & 3) == 0) {  // one accumulator per wave (its four lane groups share the maximum)
+          o0 += w * part_o[x >> 2][hh][d0];
+          o1 += w * part_o[x >> 2][hh][d0 + 1];
+        }
+      } else {
+        o0 += w * part_o[x][hh][d0];
+        o1 += w * part_o[x][hh][d0 + 1];
+      }
     }
     const int head = head0 + hh;
     if (slot >= 0) {
@@ -385,11 +475,17 @@ int launch_decode(const DecodeParams& p, bool bf16, bool paged, hipStream_t s) {
   if (grid <= 0) return TMX_OK;
   TMX_CHECK_SUPPORTED(grid < (1ll << 31), "decode kernel: too many work items");
   const unsigned gsz = (unsigned)grid;
-  // (instantiations: cache type x scales x heads per workgroup)
+  // (instantiations: cache type x scales x heads per workgroup x where the weighted sum runs)
+  // The weighted sum on the matrix cores is the default: 64 x 8192 decode, 16 / 2 heads: 95 -> 83 us (16-bit
+  // cache), 92 -> 77 us (fp8); 32 / 8 heads: 337 / 185 us either way.  TMX_ATTN_DECODE_VALU selects the vector
+  // units (kept for comparison and as the second implementation the parity tests run against).
+  const bool mpv = p.valu_sum == 0;
 #define TMX_DECODE_LAUNCH(BF, PG, K8, UN)                                             \
   do {                                                                               \
-    if (p.hw == 8) decode_kernel<BF, PG, K8, UN, 8><<<gsz, 256, 0, s>>>(p);          \
-    else decode_kernel<BF, PG, K8, UN, 4><<<gsz, 256, 0, s>>>(p);                    \
+    if (p.hw == 8 && mpv) decode_kernel<BF, PG, K8, UN, 8, true><<<gsz, 256, 0, s>>>(p);   \
+    else if (p.hw == 8) decode_kernel<BF, PG, K8, UN, 8, false><<<gsz, 256, 0, s>>>(p);     \
+    else if (mpv) decode_kernel<BF, PG, K8, UN, 4, true><<<gsz, 256, 0, s>>>(p);            \
+    else decode_kernel<BF, PG, K8, UN, 4, false><<<gsz, 256, 0, s>>>(p);                    \
   } while (0)
   if (p.kv_fp8) {
     const bool unit = p.k_scale == 1.0f && p.v_scale == 1.0f;
