@@ -164,6 +164,7 @@ struct AttnParams {
   int num_qblocks;            // q-blocks of the batch
   int dense_on;               // requests of kDenseMinRows query rows or more are computed by the dense causal kernel
   int decode_on;              // one-row requests whose row is dense are computed by the decode kernel
+  int xcd_generic, xcd_band;  // workgroup -> K/V head chunk mapping that puts the chunks of a K/V head on one XCD
   int exp_mode;               // tuning builds: 1 = work-list workgroups return at once, 2 = band workgroups do
   long long units_total;      // work items x Y
   int mode, si, sl, last, tri_min_len;
@@ -327,6 +328,20 @@ __device__ __forceinline__ void fused_cache_write(const AttnParams& p) {
   }
 }
 
+// K/V head chunk and lane of workgroup `id` of a role.  Plain mapping: chunk = id % Y.  A K/V head with more than
+// four query heads is served by several chunks, which read the same keys: when the K/V heads divide the 8 XCDs
+// (consecutive workgroup ids go round the XCDs) and the role's workgroup count is a multiple of 8 x chunks, the
+// chunks of a head are placed 8 ids apart -- on the same XCD, started together, walking the same keys -- so that
+// the second one finds them in that XCD's L2 instead of fetching them again.
+struct UnitLane {
+  int kvc, lane;
+};
+__device__ __forceinline__ UnitLane unit_of(int id, int Y, int Hkv, int chunks, int xcd_map) {
+  if (!xcd_map) return UnitLane{id % Y, id / Y};
+  const int x = id & 7, c = (id >> 3) % chunks, t = (id >> 3) / chunks;
+  return UnitLane{(x % Hkv) * chunks + c, t * (8 / Hkv) + x / Hkv};
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Band path.  In a long triangle request almost every q-block is in "canonical position": 32 full rows
 // starting at a multiple of 32, none of them among the trailing dense rows, its window clear of the sink
@@ -366,9 +381,9 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 15, g = lane >> 4;
   const int hg = wave & 3, hf = wave >> 2;  // head of the group, 16-row half of the q-block
-  const int kvc = band_id % p.Y;
-  const int run = band_id / p.Y;
   const int chunks = p.G / p.Gw;
+  const UnitLane ul = unit_of(band_id, p.Y, p.Hkv, chunks, p.xcd_band);
+  const int kvc = ul.kvc, run = ul.lane;
   const int kvh = kvc / chunks;
   const int head = kvh * p.G + (kvc - kvh * chunks) * p.Gw + hg;
   const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = 2 * p.kv_stride_t;
@@ -736,12 +751,13 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   const int hg = sub & (p.Gw - 1);                  // this wave's head inside the workgroup's head group
   const int rb16 = (sub >> p.gw_shift) * 2 + half;   // its 16-row block inside the q-block
   // fixed for the workgroup: K/V head and query heads (the grid is a multiple of Y, or has <= Y workgroups)
-  const int kvc = bid % p.Y;
   const int chunks = p.G / p.Gw;
+  const UnitLane ul = unit_of(bid, p.Y, p.Hkv, chunks, p.xcd_generic);
+  const int kvc = ul.kvc;
   const int kvh = kvc / chunks;
   const int head0 = kvh * p.G + (kvc - kvh * chunks) * p.Gw;
   const int head = head0 + hg;
-  const int item0 = bid / p.Y;
+  const int item0 = ul.lane;
   const int item_step = ngrid / p.Y;
 
   const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = KVB * p.kv_stride_t;
@@ -1583,6 +1599,15 @@ static int launch_attn(const AttnParams& p_in, hipStream_t s) {
                         p.Y, resident);
     long long want = (long long)(p.num_heavy > 4 ? p.num_heavy : 4) * p.Y;
     if (want > resident) want = resident - resident % p.Y;
+    // chunks of a K/V head on one XCD (unit_of): both roles' workgroup counts become multiples of 8 x chunks
+    const int chunks = p.G / p.Gw;
+    const bool xcd = chunks > 1 && p.Hkv <= 8 && 8 % p.Hkv == 0;
+    const int unit = 8 * chunks;
+    if (xcd) {
+      want = (want + unit - 1) / unit * unit;
+      if (want > resident) want -= unit;
+    }
+    p.xcd_generic = p.xcd_band = (xcd && want >= unit) ? 1 : 0;
     p.n_generic = (int)want;
     int rl = (int)(((long long)p.num_qblocks * p.Y + cus - 1) / cus);
     rl = rl < 4 ? 4 : (rl > 64 ? 64 : rl);
@@ -1591,13 +1616,20 @@ static int launch_attn(const AttnParams& p_in, hipStream_t s) {
     if (const char* env = getenv("TMX_EXP")) p.exp_mode = atoi(env);
 #endif
     p.band_rl = rl;
-    const long long runs = ((long long)p.num_qblocks + rl - 1) / rl;
+    long long runs = ((long long)p.num_qblocks + rl - 1) / rl;
+    if (p.xcd_band) runs = (runs + 8 / p.Hkv - 1) / (8 / p.Hkv) * (8 / p.Hkv);  // (surplus runs find no q-block)
     const long long total = want + runs * p.Y;
     TMX_CHECK_SUPPORTED(total < (1ll << 31), "tmx_attention: too many workgroups");
     grid = (unsigned)total;
   } else {
     rc = persistent_grid(resident, p, &grid);
     if (rc != TMX_OK) return rc;
+    const int chunks = p.G / p.Gw;
+    const int unit = 8 * chunks;
+    if (chunks > 1 && p.Hkv <= 8 && 8 % p.Hkv == 0 && grid >= (unsigned)unit) {
+      grid -= grid % unit;
+      p.xcd_generic = 1;
+    }
     p.n_generic = (int)grid;
   }
   kernel<<<grid, 64 * kWaves, 0, s>>>(p);
@@ -1834,6 +1866,7 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.band_rl = 0;
   p.n_generic = 0;
   p.exp_mode = 0;
+  p.xcd_generic = p.xcd_band = 0;
   hipStream_t s = (hipStream_t)stream;
   if (p.dense_on) {
     DenseParams d;
