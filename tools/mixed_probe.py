@@ -41,7 +41,8 @@ for chunk in chunks + [advice]:
     idx = ops.build_block_index(cu, sl, cu_h, sl_h, 4, 32, 64, bm, 32, ops.MODES["triangle"], chunk_tiles=chunk,
                                 tri_min_len=2048, block_table=bt, page_size=page)
     ws = ops.alloc_workspace(idx, H, D, dev)
-    run = lambda: ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=ws)
+    flags = int(os.environ.get("FLAGS", "0"))   # e.g. 32 = TMX_ATTN_NO_DECODE: decode rows on the work list
+    run = lambda: ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=ws, flags=flags)
     t_end = time.perf_counter() + 0.15
     while time.perf_counter() < t_end:
         for _ in range(10):

@@ -1597,7 +1597,25 @@ static int launch_attn(const AttnParams& p_in, hipStream_t s) {
     // (measured at 32k tokens, Qwen3-8B heads: runs of 32 q-blocks 166 us, 16: 172, 8: 188).
     TMX_CHECK_SUPPORTED(resident >= p.Y, "tmx_attention: %d K/V head chunks need at least as many resident workgroups (%lld)",
                         p.Y, resident);
+    int rl = (int)(((long long)p.num_qblocks * p.Y + cus - 1) / cus);
+    rl = rl < 4 ? 4 : (rl > 64 ? 64 : rl);
+#ifdef TMX_TUNING
+    if (const char* env = getenv("TMX_BAND_RL")) rl = atoi(env);
+    if (const char* env = getenv("TMX_EXP")) p.exp_mode = atoi(env);
+#endif
+    p.band_rl = rl;
+    long long runs = ((long long)p.num_qblocks + rl - 1) / rl;
+    // Work-list workgroups: one per unit of the split q-blocks' pieces, and at least the slots the band
+    // workgroups leave free: a step may hold requests the band does not take (prompts below the length gate,
+    // chunks whose context is no multiple of 32, rows of a speculative decode), whose q-blocks are all on the
+    // list (a 2048-token prompt beside 128 decode rows: 799 us on 32 workgroups, the pieces' count, before).
+    // Workgroups that find nothing on the list return at once.
     long long want = (long long)(p.num_heavy > 4 ? p.num_heavy : 4) * p.Y;
+    {
+      const long long left = resident - runs * p.Y;
+      if (left > want) want = left - left % p.Y;
+      if (want > p.units_total && p.units_total >= p.Y) want = p.units_total - p.units_total % p.Y;
+    }
     if (want > resident) want = resident - resident % p.Y;
     // chunks of a K/V head on one XCD (unit_of): both roles' workgroup counts become multiples of 8 x chunks
     const int chunks = p.G / p.Gw;
@@ -1609,14 +1627,6 @@ static int launch_attn(const AttnParams& p_in, hipStream_t s) {
     }
     p.xcd_generic = p.xcd_band = (xcd && want >= unit) ? 1 : 0;
     p.n_generic = (int)want;
-    int rl = (int)(((long long)p.num_qblocks * p.Y + cus - 1) / cus);
-    rl = rl < 4 ? 4 : (rl > 64 ? 64 : rl);
-#ifdef TMX_TUNING
-    if (const char* env = getenv("TMX_BAND_RL")) rl = atoi(env);
-    if (const char* env = getenv("TMX_EXP")) p.exp_mode = atoi(env);
-#endif
-    p.band_rl = rl;
-    long long runs = ((long long)p.num_qblocks + rl - 1) / rl;
     if (p.xcd_band) runs = (runs + 8 / p.Hkv - 1) / (8 / p.Hkv) * (8 / p.Hkv);  // (surplus runs find no q-block)
     const long long total = want + runs * p.Y;
     TMX_CHECK_SUPPORTED(total < (1ll << 31), "tmx_attention: too many workgroups");
