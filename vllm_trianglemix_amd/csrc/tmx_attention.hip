@@ -165,7 +165,8 @@ struct AttnParams {
   int dense_on;               // requests of kDenseMinRows query rows or more are computed by the dense causal kernel
   int decode_on;              // one-row requests whose row is dense are computed by the decode kernel
   int xcd_generic, xcd_band;  // workgroup -> K/V head chunk mapping that puts the chunks of a K/V head on one XCD
-  int exp_mode;               // tuning builds: 1 = work-list workgroups return at once, 2 = band workgroups do
+  int exp_mode;               // tuning builds, bits: 1 = work-list workgroups return at once, 2 = band workgroups do,
+                              // 4 / 8 / 16 = band workgroups skip their output stores / query loads / key fetches
   long long units_total;      // work items x Y
   int mode, si, sl, last, tri_min_len;
   int bias_rows, bias_cols, bias_dtype, out_dtype;
@@ -338,6 +339,9 @@ struct UnitLane {
 };
 __device__ __forceinline__ UnitLane unit_of(int id, int Y, int Hkv, int chunks, int xcd_map) {
   if (!xcd_map) return UnitLane{id % Y, id / Y};
+  // 2: the Y units of a lane on ONE XCD (ids 8 apart), lanes round the XCDs: the workgroups of an XCD read whole
+  // rows of the query / output / cache tensors between them
+  if (xcd_map == 2) return UnitLane{(id >> 3) % Y, (id & 7) + 8 * (id / (8 * Y))};
   const int x = id & 7, c = (id >> 3) % chunks, t = (id >> 3) / chunks;
   return UnitLane{(x % Hkv) * chunks + c, t * (8 / Hkv) + x / Hkv};
 }
@@ -365,14 +369,23 @@ __device__ __forceinline__ bool band_qblock(const BandRule& r, int pos0, int n, 
          effective_mode(r.mode, n_full, r.tri_min_len) == TMX_MODE_TRIANGLE;
 }
 
+// bf16 launches: the band workgroups turn the V rows into fp16 inside LDS (every value of the bf16 range that
+// fp16 holds converts exactly; larger ones saturate at +-65504, smaller ones than 2^-24 vanish) and multiply
+// them by ONE fp16 term of the probabilities (11 bits) instead of two bf16 terms: 48 matrix instructions per
+// q-block and wave instead of 80.  0: V stays bf16, two-term probabilities.
+#ifndef TMX_BAND_V16
+#define TMX_BAND_V16 1
+#endif
+
 template <typename TR, int D, bool PAGED>
 __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned lds_base, const int band_id) {
   constexpr int KS = D / 32, DB = D / 16, ROWB = D * 2, CPR = D / 8;
   constexpr int RPP = 1024 / ROWB;   // rows per 1-KiB LDS-DMA piece
   constexpr int HALFB = 32 * ROWB;   // a 16-key half: [K 16 rows | V 16 rows]
   constexpr int NSLOT = 8;           // rolling window: 4 halves in use, 4 arriving (two q-blocks ahead)
-  constexpr int PWB = 8 / RPP;       // pieces per wave and pair of halves (8 rows of one tensor)
-  constexpr bool PRECISE = TR::kSplitP;
+  constexpr int PWB = 8 / RPP;       // pieces per wave and pair of halves
+  constexpr bool V16 = TR::kSplitP && TMX_BAND_V16 != 0;  // V converted to fp16 in LDS, one-term fp16 probabilities
+  constexpr bool PRECISE = TR::kSplitP && !V16;
   using frag = typename TR::frag;
   static_assert((NSLOT + 1) * HALFB <= kRingSlots * 64 * ROWB + kWaves * 16 * ROWB, "band window does not fit the kernel's LDS");
 
@@ -388,19 +401,27 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
   const int head = kvh * p.G + (kvc - kvh * chunks) * p.Gw + hg;
   const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = 2 * p.kv_stride_t;
 
-  // ---- LDS-DMA share of this wave: 8 rows of K or of V of one half of each pair ----
-  const int t_v = (wave & 3) >> 1;        // 0: K rows, 1: V rows
-  const int r8 = 8 * (wave & 1);          // rows r8 .. r8 + 7 of the half
-  const char* const kv_src = reinterpret_cast<const char*>(t_v ? p.v : p.k) + 2ll * kvh * p.kv_stride_h;
+  // ---- LDS-DMA share of this wave: 8 rows of one half of each pair, as 1-KiB pieces ----
+  // Two pieces per wave (head size 128): four rows of K and the same four rows of V, so that every wave has the
+  // same share of the V conversion.  One piece (head size 64): eight rows of K (waves 0, 1 of a group of four)
+  // or of V (waves 2, 3).
+  const int pc_t[2] = {PWB == 2 ? 0 : ((wave & 3) >> 1), 1};                    // piece x: 0 = K rows, 1 = V rows
+  const int pc_r = PWB == 2 ? RPP * (wave & 3) : 8 * (wave & 1);                // its first row inside the half
+  const bool wave_has_v = PWB == 2 || pc_t[0] == 1;
+  const char* kv_src[PWB];
+  const char* new_src[PWB];
   int kv_voff[PWB];
+  unsigned dma_off[PWB];
+  const int new_row_bytes = 2 * p.new_stride_t;
 #pragma unroll
   for (int x = 0; x < PWB; ++x) {
-    const int row = r8 + x * RPP + lane / CPR;
-    kv_voff[x] = row * kv_row_bytes + 16 * ((lane % CPR) ^ (t_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row)));
+    const int row = pc_r + lane / CPR;
+    kv_voff[x] = row * kv_row_bytes + 16 * ((lane % CPR) ^ (pc_t[x] ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row)));
+    kv_src[x] = reinterpret_cast<const char*>(pc_t[x] ? p.v : p.k) + 2ll * kvh * p.kv_stride_h;
+    new_src[x] = reinterpret_cast<const char*>(pc_t[x] ? p.v_new : p.k_new) + 2ll * kvh * p.new_stride_h;
+    dma_off[x] = (unsigned)(pc_t[x] * 16 * ROWB + pc_r * ROWB);
   }
-  const int new_row_bytes = 2 * p.new_stride_t;
-  const char* const new_src = reinterpret_cast<const char*>(t_v ? p.v_new : p.k_new) + 2ll * kvh * p.new_stride_h;
-  const unsigned dma_off = (unsigned)(t_v * 16 * ROWB + r8 * ROWB);
+  const unsigned conv_off = dma_off[PWB - 1];  // this wave's V piece inside a half
   const unsigned sink_base = lds_base + NSLOT * HALFB;
   auto slot_base = [&](int half_no) { return lds_base + (unsigned)(half_no % NSLOT) * HALFB; };
 
@@ -418,6 +439,9 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
   const char* const q_head = reinterpret_cast<const char*>(p.q) + 2ll * head * p.q_stride_h;
   const int q_lane = qi * q_row_bytes + 16 * g;
   auto load_q = [&](int q_tok0, frag (&q)[KS]) {
+#ifdef TMX_TUNING
+    if (p.exp_mode & 8) q_tok0 = q_tok0 & 31;  // every q-block reads the same rows (cached)
+#endif
     const char* rows = q_head + (long long)(q_tok0 + 16 * hf) * q_row_bytes;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -476,16 +500,32 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
         const int lrow = opaque(lane) / CPR;
 #pragma unroll
         for (int x = 0; x < PWB; ++x)
-          glds16_s(new_src + (off - 1), kv_voff[x] + (r8 + x * RPP + lrow) * (new_row_bytes - kv_row_bytes),
-                   half_base + dma_off + x * 1024);
+          glds16_s(new_src[x] + (off - 1), kv_voff[x] + (pc_r + lrow) * (new_row_bytes - kv_row_bytes), half_base + dma_off[x]);
         return;
       }
 #pragma unroll
-      for (int x = 0; x < PWB; ++x) glds16_s(kv_src + off, kv_voff[x], half_base + dma_off + x * 1024);
+      for (int x = 0; x < PWB; ++x) glds16_s(kv_src[x] + off, kv_voff[x], half_base + dma_off[x]);
+    };
+    // This wave's V piece of the half at half_base, bf16 -> fp16 in place (the piece has landed: the caller
+    // waited for it; the next barrier shows the result to the other waves).  A lane converts the 16 bytes it
+    // fetched.  Round-toward-zero conversion: in-range values are exact either way, larger ones saturate.
+    auto convert_v = [&](unsigned half_base) {
+      const unsigned a = half_base + conv_off + 16 * opaque(lane);
+      const uint4 raw = lds_read_b128<uint4>(a);
+      const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        o[x] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(rw[x] << 16), __uint_as_float(rw[x] & 0xffff0000u)));
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      *(__attribute__((address_space(3))) u32x4*)(uintptr_t)a = u32x4{o[0], o[1], o[2], o[3]};
     };
     // pair of halves: waves 0..3 fetch the first, waves 4..7 the second (a key below 0: nothing)
     auto issue_pair = [&](int key_a, unsigned base_a, int key_b, unsigned base_b) {
-      const int key = hf ? key_b : key_a;
+      int key = hf ? key_b : key_a;
+#ifdef TMX_TUNING
+      if ((p.exp_mode & 16) && key >= 0) key &= 127;  // every q-block fetches the same keys (cached)
+#endif
       if (key >= 0) issue_at(half_offset(key), hf ? base_b : base_a);
     };
 
@@ -510,6 +550,11 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
     load_q(q_start + 32 * k, qa);
     if (k + 1 < k_stop) issue_pair(16 * (h0 + 4), slot_base(h0 + 4), 16 * (h0 + 5), slot_base(h0 + 5));
     bool first = true;
+    // V16: the halves this wave fetched above (their V piece is converted ahead of the first barrier), and
+    // the half whose V piece it converts during the q-block before the one that reads it
+    const unsigned cv0 = hf ? slot_base(h0) : sink_base, cv1 = hf ? slot_base(h0 + 2) : slot_base(h0 + 1);
+    const unsigned cv2 = slot_base(h0 + 3);
+    unsigned cv_pending = slot_base(h0 + 4 + hf);
 
     // one q-block: its query rows are in `cur`, the next q-block's go to `nxt`
     auto one_qblock = [&](const frag (&cur)[KS], frag (&nxt)[KS]) {
@@ -518,7 +563,11 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
       if (has1) load_q(q_start + 32 * (k + 1), nxt);
       // where this wave's half of the q-block after the next one lives (a block-table lookup: asked for
       // here, used after the score products)
+#ifdef TMX_TUNING
+      const long long off2 = has2 ? half_offset((p.exp_mode & 16) ? (16 * (h0 + 6 + hf)) & 127 : 16 * (h0 + 6 + hf)) : 0;
+#else
       const long long off2 = has2 ? half_offset(16 * (h0 + 6 + hf)) : 0;
+#endif
       // Wait for this q-block's halves and query rows: what the wave issued later may stay in flight -- the
       // next q-block's pieces, the output rows stored last, the next q-block's query rows.
       {
@@ -530,6 +579,14 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
         else if (n == DB / 2) wait_vmcnt<DB / 2>();
         else if (n == DB) wait_vmcnt<DB>();
         else wait_vmcnt<0>();
+      }
+      const bool was_first = first;
+      if constexpr (V16) {
+        if (first && wave_has_v) {
+          convert_v(cv0);
+          convert_v(cv1);
+          if (!hf) convert_v(cv2);
+        }
       }
       first = false;
       TMX_STAMP(ts1);
@@ -558,7 +615,22 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
       // the halves of the q-block before this one are free: fetch the keys of the q-block after the next one
       asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3])::"memory");
       TMX_STAMP(ts3);
-      if (has2) issue_at(off2, slot_base(h0 + 6 + hf));
+      if constexpr (V16) {
+        if (has1) {
+          // The V piece this wave fetched during the previous q-block (or in the set-up) belongs to the next
+          // q-block: it has had a whole q-block to land.  Issued after it: the previous q-block's output rows
+          // and the next q-block's query rows.
+          const int st = was_first ? 0 : (p.out_dtype == TMX_F32 ? DB : DB / 2);
+          if (st == DB / 2) wait_vmcnt<KS + DB / 2>();
+          else if (st == DB) wait_vmcnt<KS + DB>();
+          else wait_vmcnt<KS>();
+          if (wave_has_v) convert_v(cv_pending);
+        }
+      }
+      if (has2) {
+        issue_at(off2, slot_base(h0 + 6 + hf));
+        cv_pending = slot_base(h0 + 6 + hf);
+      }
       TMX_STAMP(ts4);
 
       // ---- one softmax step over the 16 scores of the lane's row ----
@@ -589,8 +661,12 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
         for (int c = 0; c < 4; c += 2) {
           const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][c], mult, mneg));
           const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[u][c + 1], mult, mneg));
-          psum += p0 + p1;
-          TR::pack2(p0, p1, ph[2 * u + (c >> 1)], pl[2 * u + (c >> 1)]);
+          if constexpr (V16) {
+            ph[2 * u + (c >> 1)] = F16Traits::cvt2(p0, p1);
+          } else {
+            psum += p0 + p1;
+            TR::pack2(p0, p1, ph[2 * u + (c >> 1)], pl[2 * u + (c >> 1)]);
+          }
         }
 
       TMX_STAMP(ts5);
@@ -598,17 +674,23 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
       f32x4 acc[DB];
 #pragma unroll
       for (int db = 0; db < DB; ++db) acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // V16: the row sums come from the matrix cores too (a ones operand in V's place): they add up the SAME
+      // rounded probabilities as the weighted sum -- a constant V comes back unchanged, the rounding of a
+      // probability only shifts weight between keys -- and every lane ends with its row's total.
+      f32x4 lsum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
         const frag pf = __builtin_bit_cast(frag, make_uint4(ph[4 * st], ph[4 * st + 1], ph[4 * st + 2], ph[4 * st + 3]));
         const frag pq = __builtin_bit_cast(frag, make_uint4(pl[4 * st], pl[4 * st + 1], pl[4 * st + 2], pl[4 * st + 3]));
+        if constexpr (V16) lsum = F16Traits::mfma(F16Traits::ones(), __builtin_bit_cast(f16x8, pf), lsum);
         const unsigned va = gb[2 * st] + v_base, vb = gb[2 * st + 1] + v_base;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
           const s16x4 lo4 = lds_read_tr16_b64(va ^ (32 * db));
           const s16x4 hi4 = lds_read_tr16_b64(vb ^ (32 * db));
           const frag vf = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
-          acc[db] = TR::mfma(vf, pf, acc[db]);
+          if constexpr (V16) acc[db] = F16Traits::mfma(__builtin_bit_cast(f16x8, vf), __builtin_bit_cast(f16x8, pf), acc[db]);
+          else acc[db] = TR::mfma(vf, pf, acc[db]);
           if constexpr (PRECISE) acc[db] = TR::mfma(vf, pq, acc[db]);
           if ((db & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four V fragments fetched ahead
         }
@@ -616,7 +698,9 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
 
       // ---- epilogue: lane (qi, g) holds columns 16 * db + 4 * g .. + 3 of its row ----
       float l_tot;
-      {
+      if constexpr (V16) {
+        l_tot = lsum[0];
+      } else {
         const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(psum), __float_as_uint(psum), false, false);
         l_tot = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
         const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
@@ -625,6 +709,11 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
       const float inv = 1.0f / l_tot;
       // (element offsets of the wave's 16 rows stay below 2^31: the strides are checked on the host)
       const long long orows = (long long)(q_start + 32 * k + 16 * hf) * p.out_stride_t + (long long)head * p.out_stride_h;
+#ifdef TMX_TUNING
+      if ((p.exp_mode & 4) && inv != 12345.f) {
+        // no stores: the wait counts below still hold (they only wait longer)
+      } else
+#endif
       if (p.out_dtype == TMX_F32) {
         float* po = reinterpret_cast<float*>(p.out) + orows + (qi * p.out_stride_t + 4 * g);
 #pragma unroll
@@ -639,6 +728,12 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
           const uint2 bu = make_uint2(TR::cvt2(ob[0], ob[1]), TR::cvt2(ob[2], ob[3]));
           const auto r0 = __builtin_amdgcn_permlane16_swap(au.x, bu.x, false, false);
           const auto r1 = __builtin_amdgcn_permlane16_swap(au.y, bu.y, false, false);
+#ifdef TMX_TUNING
+          if (p.exp_mode & 32) {
+            *reinterpret_cast<uint4*>(po + 32 * c) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            continue;
+          }
+#endif
           store_stream16(po + 32 * c, make_uint4(r0[0], r1[0], r0[1], r1[1]));
         }
       }
@@ -737,14 +832,14 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   if constexpr (!HAS_BIAS && !FP8) {
     if (bid >= ngrid) {
 #ifdef TMX_TUNING
-      if (p.exp_mode == 2) return;
+      if (p.exp_mode & 2) return;
 #endif
       band_body<TR, D, PAGED>(p, lds_base, bid - ngrid);
       return;
     }
   }
 #ifdef TMX_TUNING
-  if (p.exp_mode == 1) return;
+  if (p.exp_mode & 1) return;
 #endif
 
   const int sub = wave & 3, half = wave >> 2;
@@ -1628,6 +1723,14 @@ static int launch_attn(const AttnParams& p_in, hipStream_t s) {
     p.xcd_generic = p.xcd_band = (xcd && want >= unit) ? 1 : 0;
     p.n_generic = (int)want;
     if (p.xcd_band) runs = (runs + 8 / p.Hkv - 1) / (8 / p.Hkv) * (8 / p.Hkv);  // (surplus runs find no q-block)
+#ifdef TMX_TUNING
+    if (const char* env = getenv("TMX_BAND_MAP")) {
+      if (atoi(env) == 2 && !p.xcd_band) {
+        p.xcd_band = 2;
+        runs = (runs + 7) / 8 * 8;
+      }
+    }
+#endif
     const long long total = want + runs * p.Y;
     TMX_CHECK_SUPPORTED(total < (1ll << 31), "tmx_attention: too many workgroups");
     grid = (unsigned)total;
