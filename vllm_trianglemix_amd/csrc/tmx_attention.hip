@@ -423,7 +423,7 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
   }
   const unsigned conv_off = dma_off[PWB - 1];  // this wave's V piece inside a half
   const unsigned sink_base = lds_base + NSLOT * HALFB;
-  auto slot_base = [&](int half_no) { return lds_base + (unsigned)(half_no % NSLOT) * HALFB; };
+  auto slot_base = [&](int half_no) { return lds_base + ((unsigned)half_no % NSLOT) * HALFB; };  // (half numbers are >= 0)
 
   // ---- compute side: per-lane read offsets inside a half, lane-constant masks ----
   const int k_base = qi * ROWB + 16 * (g ^ k_chunk_swizzle<D>(qi));
@@ -599,16 +599,27 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
       f32x4 sc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) sc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // The K fragments of two k-steps are in flight at a time (eight LDS reads, 32 registers), read by
+      // instructions the compiler cannot reorder and waited for by count: left to itself the register-minimising
+      // scheduler reads one fragment, waits for it, multiplies, sixteen times over.
       auto scores = [&](const frag (&qf)[KS]) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        u32x4 kf[2][4];
+        auto fetch = [&](int ks, u32x4 (&dst)[4]) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dst[u]) : "v"((gb[u] + k_base) ^ (64 * ks)) : "memory");
+        };
+        fetch(0, kf[0]);
+        if constexpr (KS > 1) fetch(1, kf[1]);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+          u32x4(&cur)[4] = kf[ks & 1];
+          if (ks + 1 < KS) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const frag kf = lds_read_b128<frag>((gb[u] + k_base) ^ (64 * ks));
-            sc[u] = TR::mfma(kf, qf[ks], sc[u]);
-          }
-          // (the scheduler would otherwise fetch all sixteen K fragments ahead: 64 registers)
-          if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+          for (int u = 0; u < 4; ++u) sc[u] = TR::mfma(__builtin_bit_cast(frag, cur[u]), qf[ks], sc[u]);
+          if (ks + 2 < KS) fetch(ks + 2, cur);
         }
       };
       scores(cur);
