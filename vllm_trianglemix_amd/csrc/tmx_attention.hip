@@ -369,12 +369,21 @@ __device__ __forceinline__ bool band_qblock(const BandRule& r, int pos0, int n, 
          effective_mode(r.mode, n_full, r.tri_min_len) == TMX_MODE_TRIANGLE;
 }
 
-// bf16 launches: the band workgroups turn the V rows into fp16 inside LDS (every value of the bf16 range that
-// fp16 holds converts exactly; larger ones saturate at +-65504, smaller ones than 2^-24 vanish) and multiply
-// them by ONE fp16 term of the probabilities (11 bits) instead of two bf16 terms: 48 matrix instructions per
-// q-block and wave instead of 80.  0: V stays bf16, two-term probabilities.
-#ifndef TMX_BAND_V16
-#define TMX_BAND_V16 1
+// bf16 launches: the V rows are turned into fp16 inside LDS by the waves that fetched them (every value of the
+// bf16 range that fp16 holds converts exactly; larger ones saturate at +-65504, smaller ones than 2^-24 vanish)
+// and multiplied by ONE fp16 term of the probabilities (11 bits) instead of two bf16 terms (band workgroups: 34
+// matrix instructions per q-block and wave instead of 50; work list: 24 per tile instead of 40), and the row
+// sums come from the matrix cores as well (a ones operand in V's place: they add up the same rounded
+// probabilities as the weighted sum, so that rounding a probability only shifts weight between keys).
+// 0: V stays bf16, two-term probabilities.
+#ifndef TMX_V16
+#define TMX_V16 1
+#endif
+// The same for the workgroups that walk the work list: off.  There the conversion falls to the four waves that
+// fetch the tiles and run the scalar walk, which every tile step already waits for: measured at 32k tokens,
+// Qwen3-8B heads, same box, the kernel went from 157.5 to 165.8 us with it (parity tests green either way).
+#ifndef TMX_V16_LIST
+#define TMX_V16_LIST 0
 #endif
 
 template <typename TR, int D, bool PAGED>
@@ -384,7 +393,7 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
   constexpr int HALFB = 32 * ROWB;   // a 16-key half: [K 16 rows | V 16 rows]
   constexpr int NSLOT = 8;           // rolling window: 4 halves in use, 4 arriving (two q-blocks ahead)
   constexpr int PWB = 8 / RPP;       // pieces per wave and pair of halves
-  constexpr bool V16 = TR::kSplitP && TMX_BAND_V16 != 0;  // V converted to fp16 in LDS, one-term fp16 probabilities
+  constexpr bool V16 = TR::kSplitP && TMX_V16 != 0;  // V converted to fp16 in LDS, one-term fp16 probabilities
   constexpr bool PRECISE = TR::kSplitP && !V16;
   using frag = typename TR::frag;
   static_assert((NSLOT + 1) * HALFB <= kRingSlots * 64 * ROWB + kWaves * 16 * ROWB, "band window does not fit the kernel's LDS");
@@ -821,8 +830,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   // the arithmetic (measured: 4 walkers against 8: dense-causal -10 %, sparse rows -5 %; 2 against 4: no change).
   constexpr int kIssuers = 4;
   constexpr int PW = PE / kIssuers;     // ... fetched by each issuing wave
-  constexpr bool PRECISE = TR::kSplitP; // P as a sum of two 16-bit terms
-  static_assert(PW >= 1 && NS >= 3, "ring too small");
+  constexpr bool V16L = TR::kSplitP && !FP8 && TMX_V16_LIST != 0;  // V tiles turned into fp16 inside the ring, one-term P
+  constexpr bool PRECISE = TR::kSplitP && !V16L;               // P as a sum of two 16-bit terms
+  constexpr bool SPLIT = V16L;          // an issuing wave fetches K rows and V rows (else: rows of one tensor)
+  static_assert(PW >= 1 && NS >= 3 && (!SPLIT || PW % 2 == 0), "ring too small");
   using frag = typename TR::frag;
 
   __shared__ __attribute__((aligned(1024))) char lds[NS * ENTRY + IMG + kWaves * QREG];
@@ -869,28 +880,44 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = KVB * p.kv_stride_t;
 
   // ---- LDS-DMA issue: wave-uniform bases + per-lane constant byte offsets ----
-  // Issuing wave w fetches pieces w * PW .. + PW - 1 of every K/V entry (one 16-key half of K or
-  // of V) and all QP pieces of its own Q region.
+  // Issuing wave w fetches PW pieces of every K/V entry, all of them rows of ONE 16-key half of the tile (one
+  // page of a 16-key-page cache), and all QP pieces of its own Q region: sixteen rows of one tensor, or, with the
+  // V conversion on (V16L), eight rows of K and the same eight rows of V, so that every issuing wave has the
+  // same share of it.
   const int piece_row = lane / CPR;  // row of this lane inside a 1-KiB piece
   const int piece_cc = lane % CPR;   // its 16-byte chunk
   const bool issuer = p.issue_hi ? (wave >= kWaves - kIssuers) : (wave < kIssuers);
-  const int pi0 = (wave % kIssuers) * PW;
-  const bool iss_v = pi0 >= PT;
-  const int pit0 = pi0 % PT;
-  const bool iss_second = pit0 * KRPP >= 16;  // keys 16..31 of the tile
-  const char* const kv_iss =
-      reinterpret_cast<const char*>(iss_v ? p.v : p.k) + (long long)KVB * kvh * p.kv_stride_h;
-  // (two sources: the same tensor of the step's own rows)
+  const int iw = wave % kIssuers;
+  // piece x: tensor (false K, true V), first row inside the tile, byte offset inside the ring entry
+  bool pc_v[PW];
+  int pc_row[PW];
+  unsigned pc_dst[PW];
+#pragma unroll
+  for (int x = 0; x < PW; ++x) {
+    if constexpr (SPLIT) {
+      pc_v[x] = x >= PW / 2;
+      pc_row[x] = 8 * iw + KRPP * (x % (PW / 2));
+    } else {
+      pc_v[x] = iw * PW + x >= PT;
+      pc_row[x] = ((iw * PW + x) % PT) * KRPP;
+    }
+    pc_dst[x] = (unsigned)(((pc_v[x] ? PT : 0) + pc_row[x] / KRPP) * 1024);
+  }
+  const bool iss_second = pc_row[0] >= 16;  // keys 16..31 of the tile
+  const char* const k_iss = reinterpret_cast<const char*>(p.k) + (long long)KVB * kvh * p.kv_stride_h;
+  const char* const v_iss = reinterpret_cast<const char*>(p.v) + (long long)KVB * kvh * p.kv_stride_h;
+  // (two sources: the same tensors of the step's own rows)
   const int new_row_bytes = 2 * p.new_stride_t;
-  const char* const kn_iss = reinterpret_cast<const char*>(iss_v ? p.v_new : p.k_new) + 2ll * kvh * p.new_stride_h;
+  const char* const kn_iss = reinterpret_cast<const char*>(p.k_new) + 2ll * kvh * p.new_stride_h;
+  const char* const vn_iss = reinterpret_cast<const char*>(p.v_new) + 2ll * kvh * p.new_stride_h;
   const char* const q_own = reinterpret_cast<const char*>(p.q) + 2ll * head * p.q_stride_h;
   const unsigned q_lds = lds_base + NS * ENTRY + IMG + wave * QREG;
   int kv_voff[PW], q_voff[QP];
 #pragma unroll
   for (int x = 0; x < PW; ++x) {
-    const int row = (pit0 + x) * KRPP + lane / KCPR;
+    const int row = pc_row[x] + lane / KCPR;
     // (the 16-bit images are chunk-swizzled on their way in; fp8 tiles land as they are)
-    const int swz = FP8 ? 0 : (iss_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row));
+    const int swz = FP8 ? 0 : (pc_v[x] ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row));
     kv_voff[x] = row * kv_row_bytes + 16 * ((lane % KCPR) ^ swz);
   }
 #pragma unroll
@@ -1018,7 +1045,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   };
 
   auto issue_one = [&]() {
-    const unsigned dst = lds_base + (unsigned)gi_slot * ENTRY + pi0 * 1024;
+    const unsigned dst = lds_base + (unsigned)gi_slot * ENTRY;
     const int n = i_n;
     {
       const int j0 = d_tile * kBlockN;
@@ -1036,7 +1063,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
           const int lrow = opaque(lane) / KCPR;
 #pragma unroll
           for (int x = 0; x < PW; ++x)
-            glds16_s(kn_iss + bb, kv_voff[x] + ((pit0 + x) * KRPP + lrow) * (new_row_bytes - kv_row_bytes), dst + x * 1024);
+            glds16_s((pc_v[x] ? vn_iss : kn_iss) + bb, kv_voff[x] + (pc_row[x] + lrow) * (new_row_bytes - kv_row_bytes),
+                     dst + pc_dst[x]);
         } else {
           long long bb;
           if constexpr (PAGED) {
@@ -1046,14 +1074,14 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
             bb = (i_krow0 + j0) * kv_row_bytes;
           }
 #pragma unroll
-          for (int x = 0; x < PW; ++x) glds16_s(kv_iss + bb, kv_voff[x], dst + x * 1024);
+          for (int x = 0; x < PW; ++x) glds16_s((pc_v[x] ? v_iss : k_iss) + bb, kv_voff[x], dst + pc_dst[x]);
         }
       } else {
         // last, partial tile: keys past the end are masked later; clamp their source to the last key
         const int l2 = opaque(lane);
 #pragma unroll
         for (int x = 0; x < PW; ++x) {
-          const int row = (pit0 + x) * KRPP + l2 / KCPR;
+          const int row = pc_row[x] + l2 / KCPR;
           const int j = imin(j0 + row, n - 1);
           long long off;
           if constexpr (PAGED) {
@@ -1062,12 +1090,12 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
           } else {
             off = (i_krow0 + j) * kv_row_bytes;
           }
-          const int swz = FP8 ? 0 : (iss_v ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row));
-          const char* src = kv_iss + off;
+          const int swz = FP8 ? 0 : (pc_v[x] ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row));
+          const char* src = (pc_v[x] ? v_iss : k_iss) + off;
           if constexpr (PAGED && !FP8) {
-            if (j >= i_ctx) src = kn_iss + (long long)(i_newrow0 + j) * new_row_bytes;
+            if (j >= i_ctx) src = (pc_v[x] ? vn_iss : kn_iss) + (long long)(i_newrow0 + j) * new_row_bytes;
           }
-          glds16(src + 16 * ((l2 % KCPR) ^ swz), dst + x * 1024);
+          glds16(src + 16 * ((l2 % KCPR) ^ swz), dst + pc_dst[x]);
         }
       }
     }
@@ -1107,13 +1135,45 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   const unsigned long long t_begin = ts4;
 #endif
 
+  // V16L: the V pieces an issuing wave fetched are turned into fp16 in place by that wave (a lane converts the 16
+  // bytes it fetched; round toward zero: in-range values are exact either way, larger ones saturate), one step
+  // ahead of the tile's use -- the piece has had two steps to land, and the barrier that opens the next step
+  // shows the result to the other waves.  conv_next: the next ring entry whose V this wave has not converted.
+  int conv_next = 0;
+  // this wave's pieces of ring entry e have landed when at most this many of its later operations are in flight
+  auto wait_entry = [&](int e) {
+    wait_vmcnt_levels<PW>(PW * (gi - e - 1) + (e < store_mark ? store_ops : 0) + (e < q_mark ? q_ops : 0));
+  };
+  auto convert_v_pieces = [&](int slot) {
+    const unsigned eb = lds_base + (unsigned)slot * ENTRY + 16u * (unsigned)lane_now();
+#pragma unroll
+    for (int x = PW / 2; x < PW; ++x) {
+      const unsigned a = eb + pc_dst[x];
+      const uint4 raw = lds_read_b128<uint4>(a);
+      const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+        o[y] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(rw[y] << 16), __uint_as_float(rw[y] & 0xffff0000u)));
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      *(__attribute__((address_space(3))) u32x4*)(uintptr_t)a = u32x4{o[0], o[1], o[2], o[3]};
+    }
+  };
+
   // Wait for ring entries gs .. gs + cnt - 1, make them visible to the workgroup, then refill the
   // slots the previous step freed (entries below gs are consumed once every wave is past the barrier).
   auto step_sync = [&](int cnt) {
     TMX_STAMP(ts0);
-    if (issuer)
-      wait_vmcnt_levels<PW>(PW * (gi - gs - cnt) + (gs + cnt - 1 < store_mark ? store_ops : 0) +
-                            (gs + cnt - 1 < q_mark ? q_ops : 0));
+    if (issuer) {
+      wait_entry(gs + cnt - 1);
+      if constexpr (V16L) {
+        // (only the first entry of a run of items, or an entry issued too late to be converted a step ahead)
+        if (conv_next == gs) {
+          convert_v_pieces(gs_slot);
+          ++conv_next;
+        }
+      }
+    }
     TMX_STAMP(ts1);
 #ifndef TMX_ABLATE_BARRIER
     // every LDS read of the entries about to be overwritten has returned before the barrier
@@ -1267,6 +1327,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 #pragma unroll
     for (int db = 0; db < DB; ++db) acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = kMinusBig, l_run = 0.f;
+    f32x4 lacc = f32x4{0.f, 0.f, 0.f, 0.f};  // V16L: the row sums, accumulated by the matrix cores (every lane: its row's total)
 
     // One softmax step over CNT key tiles (ring entries gs .. gs + CNT - 1).
     // One softmax step over ONE 16-key half (kb) of the tile: the sink tile and the window's edge
@@ -1318,6 +1379,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         l_run *= alpha;
+        if constexpr (V16L) lacc *= alpha;
         if (!first) {
 #pragma unroll
           for (int db = 0; db < DB; ++db) acc[db] *= alpha;
@@ -1331,15 +1393,25 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[1], mult, -m_new));
         const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2], mult, -m_new));
         const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[3], mult, -m_new));
-        psum = (p0 + p1) + (p2 + p3);
-        TR::pack2(p0, p1, ph.x, pl2.x);
-        TR::pack2(p2, p3, ph.y, pl2.y);
+        if constexpr (V16L) {
+          ph.x = F16Traits::cvt2(p0, p1);
+          ph.y = F16Traits::cvt2(p2, p3);
+        } else {
+          psum = (p0 + p1) + (p2 + p3);
+          TR::pack2(p0, p1, ph.x, pl2.x);
+          TR::pack2(p2, p3, ph.y, pl2.y);
+        }
       }
       l_run += psum;
+      if constexpr (V16L) {
+        const s16x4 ones4 = __builtin_bit_cast(s16x4, make_uint2(0x3C003C00u, 0x3C003C00u));
+        lacc = F16Traits::mfma16(ones4, ph, lacc);
+      }
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
         const s16x4 v4 = lds_read_tr16_b64(vl ^ (32 * db));
-        acc[db] = TR::mfma16(v4, ph, acc[db]);
+        if constexpr (V16L) acc[db] = F16Traits::mfma16(v4, ph, acc[db]);
+        else acc[db] = TR::mfma16(v4, ph, acc[db]);
         if constexpr (PRECISE) acc[db] = TR::mfma16(v4, pl2, acc[db]);
       }
     };
@@ -1427,6 +1499,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_next);
         m_run = m_next;
         l_run *= alpha;
+        if constexpr (V16L) lacc *= alpha;
         if (!first) {
 #pragma unroll
           for (int db = 0; db < DB; ++db) acc[db] *= alpha;
@@ -1444,11 +1517,16 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
           const f32x2 e = f32x2{s[u][c >> 2][c & 3], s[u][c >> 2][(c & 3) + 1]} * mult2 + mneg2;
           const float p0 = __builtin_amdgcn_exp2f(e[0]);
           const float p1 = __builtin_amdgcn_exp2f(e[1]);
-          psum2 += f32x2{p0, p1};
-          TR::pack2(p0, p1, hi[c >> 1], lo[c >> 1]);
+          if constexpr (V16L) {
+            hi[c >> 1] = F16Traits::cvt2(p0, p1);
+          } else {
+            psum2 += f32x2{p0, p1};
+            TR::pack2(p0, p1, hi[c >> 1], lo[c >> 1]);
+          }
         }
         pf[u] = __builtin_bit_cast(frag, make_uint4(hi[0], hi[1], hi[2], hi[3]));
         if constexpr (PRECISE) pl[u] = __builtin_bit_cast(frag, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+        if constexpr (V16L) lacc = F16Traits::mfma(F16Traits::ones(), __builtin_bit_cast(f16x8, pf[u]), lacc);
       }
       l_run += psum2[0] + psum2[1];
 
@@ -1460,7 +1538,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
           const s16x4 lo4 = lds_read_tr16_b64(vl[u] ^ (32 * db));
           const s16x4 hi4 = lds_read_tr16_b64((vl[u] ^ (32 * db)) + 16 * ROWB);
           const frag vf = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
-          acc[db] = TR::mfma(vf, pf[u], acc[db]);
+          if constexpr (V16L) acc[db] = F16Traits::mfma(__builtin_bit_cast(f16x8, vf), __builtin_bit_cast(f16x8, pf[u]), acc[db]);
+          else acc[db] = TR::mfma(vf, pf[u], acc[db]);
           if constexpr (PRECISE) acc[db] = TR::mfma(vf, pl[u], acc[db]);
         }
       TMX_STAMP(ts1);
@@ -1491,6 +1570,14 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       gs += cnt;
       gs_slot = slot_after(gs_slot, cnt);
       t = t_next;
+      if constexpr (V16L) {
+        // the next entry (of this item or of the one after it), issued two steps ago
+        if (issuer && conv_next == gs && conv_next < gi) {
+          wait_entry(conv_next);
+          convert_v_pieces(gs_slot);
+          ++conv_next;
+        }
+      }
     }
     TMX_STAMP(ts0);
 
@@ -1498,7 +1585,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     int stores = 0;
     if (w_has_rows) {
       float l_tot;  // sum over the 4 lanes that share a row
-      {
+      if constexpr (V16L) {
+        l_tot = lacc[0];
+      } else {
         const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         l_tot = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
         const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
