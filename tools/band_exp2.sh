@@ -2,6 +2,8 @@
 # Tuning build only (make -C vllm_trianglemix_amd/csrc tune): kernel time of bench.py's launch with one role
 # switched off (TMX_EXP=1: band workgroups only, 2: work-list workgroups only, 0: both) per band run length.
 # usage (GPU box): CFGS="1:32 1:16 0:32" bash tools/band_exp2.sh
+[ -n "$RLS" ] && export TMX_BAND_RLS=$RLS
+[ -n "$TAU" ] && export TMX_BAND_TAU=$TAU
 export TRIANGLEMIX_BINDING=ctypes TMX_LIB_PATH=$PWD/tools/libtrianglemix_hip_tune.so
 for cfg in ${CFGS:-"0:32 1:32 1:16 1:8 2:32"}; do
   e=${cfg%%:*}; rl=${cfg##*:}

@@ -43,5 +43,12 @@ tot = st[:, :, 6].mean()
 print(f"{mode} n={n}: {len(st)} workgroups, mean total {tot:.0f} cycles (100 MHz ticks? see below), steps/wave {st[:, :, 7].mean():.1f}")
 for i, nm in enumerate(names[:6]):
     print(f"  {nm:14s} {st[:, :, i].mean():12.0f}  {100 * st[:, :, i].mean() / tot:5.1f} %   per step {st[:, :, i].mean() / st[:, :, 7].mean():8.1f}")
+wt = st[:, :, 6].max(axis=1)  # a workgroup is done when its slowest wave is
+print(f"  workgroup totals: min {wt.min():.0f}  p10 {np.percentile(wt, 10):.0f}  median {np.median(wt):.0f}  p90 {np.percentile(wt, 90):.0f}  max {wt.max():.0f}")
+if role != "band":
+    # waves 0..3 fetch the tiles and run the scalar walk, waves 4..7 only compute
+    for nm, sl_ in (("issuing waves", slice(0, 4)), ("other waves", slice(4, 8))):
+        sub = st[:, sl_, :]
+        print(f"  {nm}: " + "  ".join(f"{n} {sub[:, :, i].mean() / sub[:, :, 7].mean():.0f}" for i, n in enumerate(names[:6])) + "  (cycles per step)")
 acc = st[:, :, :6].sum(axis=2).mean()
 print(f"  unaccounted    {tot - acc:12.0f}  {100 * (tot - acc) / tot:5.1f} %")

@@ -160,13 +160,17 @@ struct AttnParams {
   int num_heavy, sched_w;     // the first num_heavy items are pieces of split q-blocks; light items per piece (schedule)
   int band_on;                // sparse q-blocks in canonical position run on the band path (their own workgroups)
   int band_rl;                // q-blocks per band workgroup
+  int band_tail0, band_rls;   // q-blocks from band_tail0 on are left to the work-list workgroups, band_rls each,
+                              // for when their list is done (band_rls = 0: none, band_tail0 = num_qblocks)
   int n_generic;              // workgroups 0 .. n_generic - 1 walk the work list, the others are band workgroups
   int num_qblocks;            // q-blocks of the batch
+  int batch, chunk_tiles;     // requests of the step; tiles per piece of a split q-block
   int dense_on;               // requests of kDenseMinRows query rows or more are computed by the dense causal kernel
   int decode_on;              // one-row requests whose row is dense are computed by the decode kernel
   int xcd_generic, xcd_band;  // workgroup -> K/V head chunk mapping that puts the chunks of a K/V head on one XCD
   int exp_mode;               // tuning builds, bits: 1 = work-list workgroups return at once, 2 = band workgroups do,
-                              // 4 / 8 / 16 = band workgroups skip their output stores / query loads / key fetches
+                              // 4 / 8 / 16 = band workgroups skip their output stores / query loads / key fetches, 32 = default-policy
+                              // output stores, 64 / 128 / 256 = whole-line / whole-row / quad-contiguous output stores (wrong placement: timing only)
   long long units_total;      // work items x Y
   int mode, si, sl, last, tri_min_len;
   int bias_rows, bias_cols, bias_dtype, out_dtype;
@@ -386,8 +390,10 @@ __device__ __forceinline__ bool band_qblock(const BandRule& r, int pos0, int n, 
 #define TMX_V16_LIST 0
 #endif
 
+// kvc: the workgroup's K/V head chunk; [qb, qb_end): its run of q-blocks.
 template <typename TR, int D, bool PAGED>
-__device__ __forceinline__ void band_body(const AttnParams& p, const unsigned lds_base, const int band_id) {
+__device__ __forceinline__ void band_body(const AttnParams& p, const unsigned lds_base, const int kvc, int qb, const int qb_end,
+                                          const bool own_stamps) {
   constexpr int KS = D / 32, DB = D / 16, ROWB = D * 2, CPR = D / 8;
   constexpr int RPP = 1024 / ROWB;   // rows per 1-KiB LDS-DMA piece
   constexpr int HALFB = 32 * ROWB;   // a 16-key half: [K 16 rows | V 16 rows]
@@ -397,6 +403,12 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
   constexpr bool PRECISE = TR::kSplitP && !V16;
   using frag = typename TR::frag;
   static_assert((NSLOT + 1) * HALFB <= kRingSlots * 64 * ROWB + kWaves * 16 * ROWB, "band window does not fit the kernel's LDS");
+  // 16-bit output rows leave through a 1-KiB stage per wave behind the window (head size 128: the window takes 72
+  // of the kernel's 80 KiB): rounds of eight half rows, written by the lanes that hold them, read back one 16-byte
+  // piece per lane in row order, so that a store instruction covers 128 contiguous bytes of each of eight rows
+  // (adjacent lanes, adjacent bytes) instead of a 64-byte piece of each of 16 rows, four lanes 16 apart each.  Same bytes, other shape: measured with the
+  // placement alone changed, band workgroups only 137.7 -> 123.1 us, the whole 32k launch 163.8 -> 153.5 us.
+  constexpr bool ROWST = (NSLOT + 1) * HALFB + kWaves * 1024 <= kRingSlots * 64 * ROWB + kWaves * 16 * ROWB;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -404,8 +416,6 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
   const int qi = lane & 15, g = lane >> 4;
   const int hg = wave & 3, hf = wave >> 2;  // head of the group, 16-row half of the q-block
   const int chunks = p.G / p.Gw;
-  const UnitLane ul = unit_of(band_id, p.Y, p.Hkv, chunks, p.xcd_band);
-  const int kvc = ul.kvc, run = ul.lane;
   const int kvh = kvc / chunks;
   const int head = kvh * p.G + (kvc - kvh * chunks) * p.Gw + hg;
   const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = 2 * p.kv_stride_t;
@@ -446,19 +456,20 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
   const float mult = p.scale_log2;
   // query rows and output rows: wave-uniform base of the wave's 16 rows + this lane's 32-bit offset
   const char* const q_head = reinterpret_cast<const char*>(p.q) + 2ll * head * p.q_stride_h;
-  const int q_lane = qi * q_row_bytes + 16 * g;
   auto load_q = [&](int q_tok0, frag (&q)[KS]) {
 #ifdef TMX_TUNING
     if (p.exp_mode & 8) q_tok0 = q_tok0 & 31;  // every q-block reads the same rows (cached)
 #endif
     const char* rows = q_head + (long long)(q_tok0 + 16 * hf) * q_row_bytes;
+    // (the lane's 32-bit offset is computed here, from the lane number: a 64-bit per-lane pointer kept across
+    // the loop was the first thing the register allocator spilled)
+    const int l = opaque(lane);
+    const unsigned qo = (unsigned)((l & 15) * q_row_bytes + 16 * (l >> 4));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-      q[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(rows + (q_lane + 64 * ks)));
+      q[ks] = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(rows + (qo + 64u * ks)));
   };
 
-  int qb = run * p.band_rl;
-  const int qb_end = imin(p.num_qblocks, qb + p.band_rl);
   bool fresh = true;  // nothing of this workgroup is in flight or being read
 #ifdef TMX_STAMPS
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -735,10 +746,73 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
       } else
 #endif
       if (p.out_dtype == TMX_F32) {
-        float* po = reinterpret_cast<float*>(p.out) + orows + (qi * p.out_stride_t + 4 * g);
+        // (wave-uniform base + a 32-bit lane offset computed here: nothing of it stays live across the loop)
+        const int l = opaque(lane);
+        char* const ob = reinterpret_cast<char*>(p.out) + 4 * orows;
+        const unsigned lo = 4u * (unsigned)((l & 15) * p.out_stride_t + 4 * (l >> 4));
 #pragma unroll
         for (int db = 0; db < DB; ++db)
-          store_stream16(po + 16 * db, make_float4(acc[db][0] * inv, acc[db][1] * inv, acc[db][2] * inv, acc[db][3] * inv));
+          store_stream16(ob + lo + 64 * db, make_float4(acc[db][0] * inv, acc[db][1] * inv, acc[db][2] * inv, acc[db][3] * inv));
+      } else if (ROWST
+#ifdef TMX_TUNING
+                 && !(p.exp_mode & (32 | 64 | 128 | 256 | 512))
+#endif
+      ) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        // two passes, one per half of the row (ROWB / 2 bytes = DB / 4 pieces per lane), each in two rounds of
+        // 2 RPP rows: the stage holds 2 RPP half rows; a store instruction covers 2 RPP rows x one half row
+#ifndef TMX_ROW_PASSES
+#define TMX_ROW_PASSES 2
+#endif
+        constexpr int NPASS = TMX_ROW_PASSES;     // passes over the row: 2 = half rows, 1 = whole rows
+        constexpr int HP = DB / 2 / NPASS;        // pieces per lane and pass
+        constexpr int HROWB = ROWB / NPASS;       // bytes of a row part
+        constexpr int RR = NPASS * RPP;           // rows per round (the stage holds 1 KiB)
+        const int l = opaque(lane);
+        const unsigned stg = lds_base + (NSLOT + 1) * HALFB + wave * 1024;  // this wave's stage (nobody else's)
+        const unsigned waddr = stg + (qi % RR) * HROWB + 2 * ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
+        // wave-uniform base of the wave's 16 output rows + this lane's 32-bit byte offset
+        char* const ob = reinterpret_cast<char*>(p.out) + 2 * orows;
+        const unsigned lo = 2u * (unsigned)((l / (CPR / NPASS)) * p.out_stride_t + 8 * (l % (CPR / NPASS)));
+#pragma unroll
+        for (int hh = 0; hh < NPASS; ++hh) {
+          u32x4 rc[HP];  // piece c of this lane's row: 8 columns at 32 c + {0, 16, 8, 24}[g]
+#pragma unroll
+          for (int x = 0; x < HP; ++x) {
+            const int c = hh * HP + x;
+            const f32x4 oa = acc[2 * c] * inv, ob = acc[2 * c + 1] * inv;
+            const uint2 au = make_uint2(TR::cvt2(oa[0], oa[1]), TR::cvt2(oa[2], oa[3]));
+            const uint2 bu = make_uint2(TR::cvt2(ob[0], ob[1]), TR::cvt2(ob[2], ob[3]));
+            const auto r0 = __builtin_amdgcn_permlane16_swap(au.x, bu.x, false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(au.y, bu.y, false, false);
+            rc[x] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+          }
+          // All rounds of the pass are issued back to back: LDS operations of a wave execute in order, so a
+          // round's read sees that round's writes and the next round's writes come after it; only the stores
+          // wait, each for its own read.  The reads are pinned by inline asm: lanes exchange data through the
+          // stage, which the compiler, reasoning about one thread, does not see -- it moved a plain read into
+          // the branch of the writing lanes, "unchanged for everyone else".
+          constexpr int NR = 16 / RR;
+          u32x4 v[NR];
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            if (qi / RR == j) {
+#pragma unroll
+              for (int x = 0; x < HP; ++x) *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(waddr + 64 * x) = rc[x];
+            }
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(stg + 16 * l) : "memory");
+          }
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            // (the count is of this wave's LDS operations after read j: the later rounds' reads; the masked
+            // writes between them only make the wait longer for the lanes that issued them)
+            if (NR - 1 - j >= 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(v[j])::"memory");
+            else if (NR - 1 - j == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(v[j])::"memory");
+            else if (NR - 1 - j == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(v[j])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[j])::"memory");
+            store_stream16(ob + (2ll * j * RR * p.out_stride_t + hh * HROWB) + lo, __builtin_bit_cast(uint4, v[j]));
+          }
+        }
       } else {
         uint16_t* po = reinterpret_cast<uint16_t*>(p.out) + orows + (qi * p.out_stride_t + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g));
 #pragma unroll
@@ -751,6 +825,29 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
 #ifdef TMX_TUNING
           if (p.exp_mode & 32) {
             *reinterpret_cast<uint4*>(po + 32 * c) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            continue;
+          }
+          if (p.exp_mode & 64) {
+            // timing experiment (wrong placement, same bytes): every store instruction covers 8 rows x 128 bytes
+            // (whole cache lines) instead of 16 rows x 64 bytes
+            uint16_t* pe = reinterpret_cast<uint16_t*>(p.out) + orows + (((qi & 7) + 8 * (c & 1)) * p.out_stride_t + 64 * (c >> 1) + 32 * (qi >> 3) + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g));
+            store_stream16(pe, make_uint4(r0[0], r1[0], r0[1], r1[1]));
+            continue;
+          }
+          if (p.exp_mode & 256) {
+            // timing experiment (wrong placement, same bytes): four adjacent lanes store 64 contiguous bytes, a
+            // 16-lane group covers 4 rows x 64 bytes, the instruction the same 16 rows x 64 bytes as the shipped one
+            const int x = qi & 3;
+            uint16_t* pe = reinterpret_cast<uint16_t*>(p.out) + orows + (((qi & 12) | g) * p.out_stride_t + 32 * c + ((x & 1) ? 16 + 4 * (x - 1) : 4 * x));
+            store_stream16(pe, make_uint4(r0[0], r1[0], r0[1], r1[1]));
+            continue;
+          }
+          if (p.exp_mode & 128) {
+            // timing experiment (wrong placement, same bytes): adjacent lanes store adjacent 16-byte pieces, an
+            // instruction covers 4 whole rows of 256 bytes
+            const int l = opaque(lane);
+            uint16_t* pe = reinterpret_cast<uint16_t*>(p.out) + orows + (((l >> 4) + 4 * c) * p.out_stride_t + 8 * (l & 15));
+            store_stream16(pe, make_uint4(r0[0], r1[0], r0[1], r1[1]));
             continue;
           }
 #endif
@@ -784,7 +881,7 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
 #ifdef TMX_STAMPS
   TMX_STAMP(ts0);
   seg[6] = ts0 - t_begin;
-  if (p.stamps != nullptr && lane == 0) {
+  if (p.stamps != nullptr && lane == 0 && own_stamps) {
     unsigned long long* dst = p.stamps + ((size_t)blockIdx.x * kWaves + wave) * 8;
     for (int x = 0; x < 8; ++x) dst[x] = seg[x];
   }
@@ -856,7 +953,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 #ifdef TMX_TUNING
       if (p.exp_mode & 2) return;
 #endif
-      band_body<TR, D, PAGED>(p, lds_base, bid - ngrid);
+      const UnitLane bl = unit_of(bid - ngrid, p.Y, p.Hkv, p.G / p.Gw, p.xcd_band);
+      const int qb0 = bl.lane * p.band_rl;
+      band_body<TR, D, PAGED>(p, lds_base, bl.kvc, qb0, imin(p.band_tail0, qb0 + p.band_rl), true);
       return;
     }
   }
@@ -1666,6 +1765,21 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     for (int x = 0; x < 8; ++x) dst[x] = seg[x];
   }
 #endif
+  // Tuning builds only (TMX_BAND_RLS): the list is done, the workgroup goes on with a share of the q-blocks the
+  // band workgroups left.  Measured slower for every share (see launch_attn), so the shipped kernel has no such role.
+#ifdef TMX_TUNING
+  if constexpr (!HAS_BIAS && !FP8) {
+    if (p.band_rls > 0) {
+      const int qb0 = p.band_tail0 + item0 * p.band_rls;
+      if (qb0 < p.num_qblocks) {
+        // every wave is done with the ring before the band's window overwrites it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        band_body<TR, D, PAGED>(p, lds_base, kvc, qb0, imin(p.num_qblocks, qb0 + p.band_rls), false);
+      }
+    }
+  }
+#endif
 }
 
 // Merge the pieces of every split q-block: out = sum_p O_p 2^(m_p - M) / sum_p l_p 2^(m_p - M).
@@ -1828,6 +1942,25 @@ static int launch_attn(const AttnParams& p_in, hipStream_t s) {
       if (atoi(env) == 2 && !p.xcd_band) {
         p.xcd_band = 2;
         runs = (runs + 7) / 8 * 8;
+      }
+    }
+#endif
+    // Tail share (tuning builds, TMX_BAND_RLS = q-blocks per work-list workgroup).  A band workgroup works for the
+    // whole launch, a work-list workgroup with one piece of the trailing dense rows for about four fifths of it,
+    // so the last q-blocks were left to the work-list workgroups for when their list is done, the band runs
+    // shortened to match.  Measured at 32k tokens, Qwen3-8B heads, one box: 162.3 us without, 167.9 / 171.9 /
+    // 174.9 / 177.6 us with 2 / 3 / 4 / 5 q-blocks per work-list workgroup -- a second band run on a CU starts
+    // with an empty pipeline and fetches 64 keys again, and the launch is bound by the memory system, which
+    // a further stream per CU does not speed up (band workgroups alone: 137.9 us with one per CU, 144.7 with two).
+    p.band_tail0 = p.num_qblocks;
+    p.band_rls = 0;
+#ifdef TMX_TUNING
+    if (const char* env = getenv("TMX_BAND_RLS")) {
+      const long long S = want / p.Y, R = runs, rls = atoi(env);
+      if (p.batch == 1 && want >= p.Y && R > 0 && rls >= 1 && rls <= 64 && S * rls < p.num_qblocks) {
+        p.band_rls = (int)rls;
+        p.band_tail0 = (int)(p.num_qblocks - S * rls);
+        p.band_rl = (int)((p.band_tail0 + R - 1) / R);
       }
     }
 #endif
@@ -2077,6 +2210,10 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
                    ? 1
                    : 0;
   p.band_rl = 0;
+  p.band_tail0 = 0;
+  p.band_rls = 0;
+  p.batch = a->batch;
+  p.chunk_tiles = ix->chunk_tiles;
   p.n_generic = 0;
   p.exp_mode = 0;
   p.xcd_generic = p.xcd_band = 0;
