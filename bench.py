@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--chunk-tiles", type=int, default=0,
                     help="piece length of the dense rows in key tiles (0: the library's advice for the batch)")
     ap.add_argument("--cpu-heads", type=int, default=8, help="heads of the CPU-baseline sample")
+    ap.add_argument("--kv-cache", choices=("model", "bf16", "fp8"), default="model",
+                    help="K/V cache type (default: the model configuration's); an A/B aid, named in config.workload")
     ap.add_argument("--no-band", action="store_true",
                     help="A/B aid: every q-block through the work list (no band workgroups for the sparse q-blocks)")
     return ap.parse_args()
@@ -253,7 +255,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
-    cfg = MODELS[args.model]
+    cfg = dict(MODELS[args.model])
+    if args.kv_cache != "model":
+        cfg["kv"] = args.kv_cache
     n = args.seq_len or cfg["seq_len"]
     if args.dry_run:
         return dry_run(args, cfg, n, world, rank)

@@ -391,14 +391,21 @@ __device__ __forceinline__ bool band_qblock(const BandRule& r, int pos0, int n, 
 #endif
 
 // kvc: the workgroup's K/V head chunk; [qb, qb_end): its run of q-blocks.
-template <typename TR, int D, bool PAGED>
+// FP8: K and V are an fp8 (e4m3fn) paged cache.  The wave that fetches eight rows of a half (1 KiB of fp8 bytes)
+// lands them in the first half of those rows' own place in the window and, one q-block ahead of their use like the
+// V conversion of bf16 launches, expands them there into the 16-bit image the arithmetic reads: value x scale
+// rounded once to the 16-bit type of q (the descale of the reference's attention kernels,
+// vllm/v1/attention/backends/rocm_attn.py:421-422); V of a bf16 launch goes on from that bf16 value to fp16 (exact).
+template <typename TR, int D, bool PAGED, bool FP8 = false>
 __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned lds_base, const int kvc, int qb, const int qb_end,
                                           const bool own_stamps) {
   constexpr int KS = D / 32, DB = D / 16, ROWB = D * 2, CPR = D / 8;
   constexpr int RPP = 1024 / ROWB;   // rows per 1-KiB LDS-DMA piece
   constexpr int HALFB = 32 * ROWB;   // a 16-key half: [K 16 rows | V 16 rows]
   constexpr int NSLOT = 8;           // rolling window: 4 halves in use, 4 arriving (two q-blocks ahead)
-  constexpr int PWB = 8 / RPP;       // pieces per wave and pair of halves
+  constexpr int KVB = FP8 ? 1 : 2;   // bytes per K/V element in memory
+  constexpr int PWB = FP8 ? 1 : 8 / RPP;  // pieces per wave and pair of halves
+  static_assert(!FP8 || (D == 128 && PAGED), "fp8 K/V: paged cache, head size 128");
   constexpr bool V16 = TR::kSplitP && TMX_V16 != 0;  // V converted to fp16 in LDS, one-term fp16 probabilities
   constexpr bool PRECISE = TR::kSplitP && !V16;
   using frag = typename TR::frag;
@@ -418,15 +425,17 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
   const int chunks = p.G / p.Gw;
   const int kvh = kvc / chunks;
   const int head = kvh * p.G + (kvc - kvh * chunks) * p.Gw + hg;
-  const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = 2 * p.kv_stride_t;
+  const int q_row_bytes = 2 * p.q_stride_t, kv_row_bytes = KVB * p.kv_stride_t;
 
   // ---- LDS-DMA share of this wave: 8 rows of one half of each pair, as 1-KiB pieces ----
   // Two pieces per wave (head size 128): four rows of K and the same four rows of V, so that every wave has the
   // same share of the V conversion.  One piece (head size 64): eight rows of K (waves 0, 1 of a group of four)
   // or of V (waves 2, 3).
+  // fp8: one piece too, eight rows of 128 bytes.
   const int pc_t[2] = {PWB == 2 ? 0 : ((wave & 3) >> 1), 1};                    // piece x: 0 = K rows, 1 = V rows
   const int pc_r = PWB == 2 ? RPP * (wave & 3) : 8 * (wave & 1);                // its first row inside the half
   const bool wave_has_v = PWB == 2 || pc_t[0] == 1;
+  const bool wave_converts = FP8 || (V16 && wave_has_v);
   const char* kv_src[PWB];
   const char* new_src[PWB];
   int kv_voff[PWB];
@@ -434,9 +443,14 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
   const int new_row_bytes = 2 * p.new_stride_t;
 #pragma unroll
   for (int x = 0; x < PWB; ++x) {
-    const int row = pc_r + lane / CPR;
-    kv_voff[x] = row * kv_row_bytes + 16 * ((lane % CPR) ^ (pc_t[x] ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row)));
-    kv_src[x] = reinterpret_cast<const char*>(pc_t[x] ? p.v : p.k) + 2ll * kvh * p.kv_stride_h;
+    if constexpr (FP8) {
+      // (the fp8 rows land as they are: lane L's 16 bytes are bytes 16 (L % 8) .. of row pc_r + L / 8)
+      kv_voff[x] = (pc_r + lane / 8) * kv_row_bytes + 16 * (lane % 8);
+    } else {
+      const int row = pc_r + lane / CPR;
+      kv_voff[x] = row * kv_row_bytes + 16 * ((lane % CPR) ^ (pc_t[x] ? v_chunk_swizzle<D>(row) : k_chunk_swizzle<D>(row)));
+    }
+    kv_src[x] = reinterpret_cast<const char*>(pc_t[x] ? p.v : p.k) + (long long)KVB * kvh * p.kv_stride_h;
     new_src[x] = reinterpret_cast<const char*>(pc_t[x] ? p.v_new : p.k_new) + 2ll * kvh * p.new_stride_h;
     dma_off[x] = (unsigned)(pc_t[x] * 16 * ROWB + pc_r * ROWB);
   }
@@ -509,8 +523,8 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
     // (offsets are multiples of 16; a band request's context is a multiple of 32, so no half holds both kinds).
     auto half_offset = [&](int key0) -> long long {
       if constexpr (PAGED) {
-        if (p.k_new != nullptr && key0 >= ctx) return ((long long)(q_start - ctx + key0) * new_row_bytes) | 1;
-        return 2ll * sload(bt + (key0 >> p.page_shift)) * p.kv_stride_page + (long long)(key0 & (p.page_size - 1)) * kv_row_bytes;
+        if (!FP8 && p.k_new != nullptr && key0 >= ctx) return ((long long)(q_start - ctx + key0) * new_row_bytes) | 1;
+        return (long long)KVB * sload(bt + (key0 >> p.page_shift)) * p.kv_stride_page + (long long)(key0 & (p.page_size - 1)) * kv_row_bytes;
       } else {
         return (krow0 + key0) * kv_row_bytes;
       }
@@ -530,15 +544,45 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
     // waited for it; the next barrier shows the result to the other waves).  A lane converts the 16 bytes it
     // fetched.  Round-toward-zero conversion: in-range values are exact either way, larger ones saturate.
     auto convert_v = [&](unsigned half_base) {
-      const unsigned a = half_base + conv_off + 16 * opaque(lane);
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      const int l = opaque(lane);
+      const unsigned a = half_base + conv_off + 16 * l;
       const uint4 raw = lds_read_b128<uint4>(a);
       const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
-      uint32_t o[4];
+      if constexpr (FP8) {
+        // 16 fp8 values of row crow -> two 16-byte chunks of its 16-bit image, swizzled as the arithmetic reads it.
+        // Every lane of the wave has its raw bytes before any lane writes (the piece and its image are this wave's).
+        const bool cv = pc_t[0] != 0;
+        const int crow = pc_r + (l >> 3), cc = l & 7;
+        const float sc = cv ? p.v_scale : p.k_scale;
+        uint32_t o[8];
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
-        o[x] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(rw[x] << 16), __uint_as_float(rw[x] & 0xffff0000u)));
-      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-      *(__attribute__((address_space(3))) u32x4*)(uintptr_t)a = u32x4{o[0], o[1], o[2], o[3]};
+        for (int x = 0; x < 4; ++x) {
+          const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)rw[x], false);
+          const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)rw[x], true);
+          o[2 * x] = TR::cvt2(lo[0] * sc, lo[1] * sc);
+          o[2 * x + 1] = TR::cvt2(hi[0] * sc, hi[1] * sc);
+        }
+        if constexpr (V16) {
+          if (cv) {
+            // the bf16 values (what the descale produces), carried on to fp16
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+              o[x] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(o[x] << 16), __uint_as_float(o[x] & 0xffff0000u)));
+          }
+        }
+        const int swz = cv ? v_chunk_swizzle<D>(crow) : k_chunk_swizzle<D>(crow);
+        const unsigned img = half_base + (cv ? 16 * ROWB : 0) + crow * ROWB;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(img + 16 * ((2 * cc) ^ swz)) = u32x4{o[0], o[1], o[2], o[3]};
+        *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(img + 16 * ((2 * cc + 1) ^ swz)) = u32x4{o[4], o[5], o[6], o[7]};
+      } else {
+        uint32_t o[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          o[x] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(rw[x] << 16), __uint_as_float(rw[x] & 0xffff0000u)));
+        *(__attribute__((address_space(3))) u32x4*)(uintptr_t)a = u32x4{o[0], o[1], o[2], o[3]};
+      }
     };
     // pair of halves: waves 0..3 fetch the first, waves 4..7 the second (a key below 0: nothing)
     auto issue_pair = [&](int key_a, unsigned base_a, int key_b, unsigned base_b) {
@@ -601,8 +645,8 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
         else wait_vmcnt<0>();
       }
       const bool was_first = first;
-      if constexpr (V16) {
-        if (first && wave_has_v) {
+      if constexpr (V16 || FP8) {
+        if (first && wave_converts) {
           convert_v(cv0);
           convert_v(cv1);
           if (!hf) convert_v(cv2);
@@ -646,7 +690,7 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
       // the halves of the q-block before this one are free: fetch the keys of the q-block after the next one
       asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3])::"memory");
       TMX_STAMP(ts3);
-      if constexpr (V16) {
+      if constexpr (V16 || FP8) {
         if (has1) {
           // The V piece this wave fetched during the previous q-block (or in the set-up) belongs to the next
           // q-block: it has had a whole q-block to land.  Issued after it: the previous q-block's output rows
@@ -655,7 +699,7 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
           if (st == DB / 2) wait_vmcnt<KS + DB / 2>();
           else if (st == DB) wait_vmcnt<KS + DB>();
           else wait_vmcnt<KS>();
-          if (wave_has_v) convert_v(cv_pending);
+          if (wave_converts) convert_v(cv_pending);
         }
       }
       if (has2) {
@@ -948,14 +992,14 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   if constexpr (PAGED && !FP8) {
     if (p.cache_slots != nullptr) fused_cache_write<D>(p);
   }
-  if constexpr (!HAS_BIAS && !FP8) {
+  if constexpr (!HAS_BIAS) {
     if (bid >= ngrid) {
 #ifdef TMX_TUNING
       if (p.exp_mode & 2) return;
 #endif
       const UnitLane bl = unit_of(bid - ngrid, p.Y, p.Hkv, p.G / p.Gw, p.xcd_band);
       const int qb0 = bl.lane * p.band_rl;
-      band_body<TR, D, PAGED>(p, lds_base, bl.kvc, qb0, imin(p.band_tail0, qb0 + p.band_rl), true);
+      band_body<TR, D, PAGED, FP8>(p, lds_base, bl.kvc, qb0, imin(p.band_tail0, qb0 + p.band_rl), true);
       return;
     }
   }
@@ -1897,7 +1941,7 @@ static int launch_attn(const AttnParams& p_in, hipStream_t s) {
   if (rc != TMX_OK) return rc;
   AttnParams p = p_in;
   unsigned grid = 0;
-  if (HAS_BIAS || FP8) p.band_on = 0;
+  if (HAS_BIAS) p.band_on = 0;
   if (p.band_on) {
     // Work-list workgroups: one per unit of the split q-blocks' pieces (they also take the few unsplit
     // q-blocks outside the canonical positions); band workgroups: runs of band_rl q-blocks per unit, about
