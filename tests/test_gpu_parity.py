@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import trianglemix_oracle as orc
-from vllm_trianglemix_amd._lib import TMX_ATTN_SHORT_QUERIES
+from vllm_trianglemix_amd._lib import TMX_ATTN_NO_BAND, TMX_ATTN_SHORT_QUERIES
 
 pytestmark = pytest.mark.gpu
 
