@@ -36,7 +36,9 @@
 extern "C" {
 #endif
 
-#define TMX_ABI_VERSION 3
+#define TMX_ABI_VERSION 4
+/* int32 entries of tmx_index_t.scratch for a batch of `batch` requests and a capacity of R q-blocks */
+#define TMX_INDEX_SCRATCH_INTS(batch, R) ((batch) + 1 + 2 * ((R) + 1) + 8 * ((R) / 1024 + 1))
 
 enum {
   TMX_OK = 0,
@@ -155,7 +157,8 @@ typedef struct tmx_index_t {
   int32_t* items;     /* [I][8], 16-byte aligned */
   int32_t* split_qb;  /* [S] (may be NULL when S == 0) */
   int32_t* totals;    /* [8]: R, nnz, I, partials, S, max tiles per q-block, 0, 0 -- as the kernel counted them */
-  int32_t* scratch;   /* [batch + 1 + 2 * (R + 1)] work area of the scan */
+  int32_t* scratch;   /* [batch + 1 + 2 * (R + 1) + 8 * (R / 1024 + 1)] work area of the scan
+                         (TMX_INDEX_SCRATCH_INTS) */
   /* capacities the buffers above were allocated with */
   int64_t cap_qblocks, cap_nnz, cap_items, cap_split;
   int32_t block_m, block_n, mode, chunk_tiles;

@@ -214,6 +214,12 @@ def test_block_index_large_and_many_requests():
     for n in (8192, 32768, 65536):
         _check_index(ops, [n], [n], 4, 32, 64, 16, 32, orc.MODE_TRIANGLE, chunk=64)
         _check_index(ops, [n], [n], 4, 32, 64, 64, 64, orc.MODE_TRIANGLE, chunk=64)
+    # several long prompts: split q-blocks (and their partial slots, pieces, positions in split_qb) in different
+    # blocks of 1024 q-blocks, which the builder scans side by side and joins by the blocks' totals
+    _check_index(ops, [9000, 5000, 7777, 3100, 1], [9000, 5000, 7777, 3100, 4000], 4, 32, 64, 16, 32, orc.MODE_TRIANGLE, chunk=8)
+    _check_index(ops, [2000, 6000, 40, 8000], [9000, 6000, 7777, 8100], 4, 32, 64, 32, 32, orc.MODE_TRIANGLE, chunk=16,
+                 full_lens=[9000, 6000, 9000, 8100])
+    _check_index(ops, [20000, 20000], [20000, 20000], 0, 0, 0, 16, 32, orc.MODE_CAUSAL, chunk=100)
     idx, _, _ = _build(ops, [32768], [32768], 4, 32, 64, 64, 64, orc.MODE_TRIANGLE, chunk=64)
     assert idx.nnz_tiles == 2042
     _check_index(ops, [4096], [4096], 4, 32, 64, 16, 32, orc.MODE_CAUSAL, chunk=64)
@@ -1062,7 +1068,7 @@ def test_torch_library_binding_equals_ctypes_path(monkeypatch):
                                                                     sl, last, bm, bn, mode, 0, chunk)
     i32 = lambda n: torch.empty((max(n, 1),), dtype=torch.int32, device=DEV)  # noqa: E731
     index = [i32(R + 1), i32(nnz), i32(2 * R), i32(R + 1), i32(8 * n_items), i32(n_split), i32(8),
-             i32(len(seq_lens) + 1 + 2 * (R + 1))]
+             i32(len(seq_lens) + 1 + 2 * (R + 1) + 8 * (R // 1024 + 1))]  # TMX_INDEX_SCRATCH_INTS
     tile_pages = i32(2 * nnz)
     C.trianglemix_build_block_index(index, tile_pages, cu, sld, torch.from_numpy(cu_h), torch.from_numpy(sl_h), btd,
                                     page, si, sl, last, bm, bn, mode, 0, chunk)

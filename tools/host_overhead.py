@@ -54,7 +54,7 @@ t_att_o = host_us(lambda: ops.attention(q, kc, vc, out, idx, cu, sld, scale, blo
 # ---- torch.ops path ----
 R, nnz, n_items, n_part, n_split, _ = C.trianglemix_index_sizes(cu_t, sl_t, si, sl, last, bm, bn, mode, 0, chunk)
 i32 = lambda m: torch.empty((max(m, 1),), dtype=torch.int32, device=dev)  # noqa: E731
-index = [i32(R + 1), i32(nnz), i32(2 * R), i32(R + 1), i32(8 * n_items), i32(n_split), i32(8), i32(2 + 2 * (R + 1))]
+index = [i32(R + 1), i32(nnz), i32(2 * R), i32(R + 1), i32(8 * n_items), i32(n_split), i32(8), i32(2 + 2 * (R + 1) + 8 * (R // 1024 + 1))]
 tile_pages = i32(2 * nnz)
 part_o = torch.empty((max(1, n_part * H * bm * D),), dtype=torch.float32, device=dev)
 part_ml = torch.empty((max(1, n_part * H * bm * 2),), dtype=torch.float32, device=dev)

@@ -14,7 +14,7 @@ TMX_OK, TMX_ERR_INVALID_ARG, TMX_ERR_UNSUPPORTED, TMX_ERR_HIP, TMX_ERR_CAPACITY 
 TMX_F32, TMX_BF16, TMX_F16, TMX_FP8_E4M3 = range(4)
 TMX_MODE_NONE, TMX_MODE_CAUSAL, TMX_MODE_TRIANGLE = range(3)
 TMX_MASK_STREAMING, TMX_MASK_LAST, TMX_MASK_MIDDLE, TMX_MASK_TRIANGLE, TMX_MASK_DENSE = range(5)
-TMX_ABI_VERSION = 3
+TMX_ABI_VERSION = 4
 
 # every symbol include/trianglemix_hip.h declares
 EXPORTED_SYMBOLS = (

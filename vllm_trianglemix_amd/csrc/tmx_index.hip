@@ -15,6 +15,11 @@
 // round, every thread still holds its q-block's numbers, and pass 2 runs inside
 // the same launch: short tile lists are written by the owning thread, long ones
 // (the dense trailing rows) by the whole workgroup.
+// Beyond 1024 q-blocks pass 1 runs on one workgroup per 1024 q-blocks
+// (index_block_kernel: prefixes inside the block, the block's totals) and pass 2
+// adds the totals of the blocks before its q-block's: no workgroup waits for
+// another, and the time no longer grows with the batch (8 prompts of 64k tokens:
+// 16 blocks side by side instead of 16 rounds on one workgroup).
 #include "tmx_common.h"
 
 namespace tmx {
@@ -72,6 +77,9 @@ struct IndexParams {
   int page_shift;
   int32_t* seq_qb_ptr;  // scratch [batch + 1]
   int32_t* piece_ptr;   // scratch [R + 1]
+  int32_t* split_pos;   // scratch [R + 1]: blocked pass 1, position of a split q-block among its block's
+  int32_t* blk_tot;     // scratch [8 x blocks]: blocked pass 1, per block (tiles, pieces, partials, split q-blocks, longest list, R)
+  int blocked;          // pass 1 ran per block of 1024 q-blocks (row_ptr / piece_ptr / part_ptr hold prefixes inside the block)
   int batch, block_m, block_n, mode, chunk, si, sl, last, tri_min_len;
   int cap_qblocks, cap_nnz, cap_items, cap_split;
   int fused;  // pass 2 inside the scan launch (host: cap_qblocks <= 1024)
@@ -315,9 +323,159 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
   }
 }
 
+// Pass 1 for more than 1024 q-blocks: workgroup k takes q-blocks 1024 k .. 1024 k + 1023.  Every workgroup
+// derives the q-blocks per request itself (the batch description is small), then writes the prefixes INSIDE its
+// block and the block's totals; index_fill_kernel adds the totals of the blocks before.
+__global__ __launch_bounds__(1024) void index_block_kernel(IndexParams p) {
+  __shared__ Int4 wave_sums[16];
+  __shared__ int s_num_qblocks;
+  __shared__ int s_qbp[1025];
+  __shared__ int4 s_req[1024];  // first query row, query rows, keys, full length
+  const bool cached = p.batch <= 1024;
+  const int tid = threadIdx.x;
+  // (a) q-blocks per request (every workgroup writes the same seq_qb_ptr values)
+  int carry = 0;
+  for (int base = 0; base < p.batch; base += 1024) {
+    const int b = base + tid;
+    int nqb = 0;
+    if (b < p.batch) {
+      const int q0 = p.cu_q[b], q1 = p.cu_q[b + 1];
+      const int rows = imax(0, q1 - q0);
+      nqb = p.bm_shift >= 0 ? (rows + p.block_m - 1) >> p.bm_shift : ceil_div(rows, p.block_m);
+      if (cached) {
+        const int n = p.seq_lens[b];
+        s_req[b] = make_int4(q0, q1 - q0, n, p.full_lens ? imax(n, p.full_lens[b]) : n);
+      }
+    }
+    Int4 tot;
+    Int4 e = block_exclusive_scan(Int4{nqb, 0, 0, 0}, wave_sums, tot);
+    if (b < p.batch) {
+      p.seq_qb_ptr[b] = carry + e.x;
+      if (cached) s_qbp[b] = carry + e.x;
+    }
+    carry += tot.x;
+  }
+  if (tid == 0) {
+    p.seq_qb_ptr[p.batch] = carry;
+    s_qbp[p.batch <= 1024 ? p.batch : 0] = carry;
+    s_num_qblocks = carry;
+  }
+  __syncthreads();
+  const int R = s_num_qblocks;
+  // (b) this block's q-blocks
+  const int qb = (int)blockIdx.x * 1024 + tid;
+  Int4 v{0, 0, 0, 0};
+  int b = 0, r0 = 0, cnt = 0;
+  if (qb < R) {
+    int lo = 0, hi = p.batch;  // last b with seq_qb_ptr[b] <= qb
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((cached ? s_qbp[mid] : p.seq_qb_ptr[mid]) <= qb) lo = mid; else hi = mid;
+    }
+    b = lo;
+    r0 = (qb - (cached ? s_qbp[b] : p.seq_qb_ptr[b])) * p.block_m;
+    int4 rq;
+    if (cached) rq = s_req[b];
+    else {
+      const int q0 = p.cu_q[b], n = p.seq_lens[b];
+      rq = make_int4(q0, p.cu_q[b + 1] - q0, n, p.full_lens ? imax(n, p.full_lens[b]) : n);
+    }
+    const int ql = rq.y, n = rq.z, nf = rq.w;
+    const int ctx = n - ql;
+    const int r1 = imin(r0 + p.block_m, ql);
+    const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si, p.sl, p.last, p.block_n, p.bn_shift);
+    cnt = tr.count();
+    const int pieces = cnt <= p.chunk ? 1 : ceil_div(cnt, p.chunk);
+    v = Int4{cnt, pieces, pieces > 1 ? pieces : 0, pieces > 1 ? 1 : 0};
+  }
+  Int4 tot;
+  const Int4 e = block_exclusive_scan(v, wave_sums, tot);
+  if (qb < R && qb < p.cap_qblocks) {
+    p.row_ptr[qb] = e.x;
+    p.piece_ptr[qb] = e.y;
+    p.part_ptr[qb] = e.z;
+    p.split_pos[qb] = e.w;
+    p.qb_meta[2 * qb] = b;
+    p.qb_meta[2 * qb + 1] = r0;
+  }
+  // longest tile list of the block (the scan's scratch is free again)
+  int m = cnt;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = imax(m, __shfl_xor(m, d, 64));
+  if ((tid & 63) == 0) wave_sums[tid >> 6].x = m;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w) m = imax(m, wave_sums[w].x);
+    int32_t* t = p.blk_tot + 8 * (int)blockIdx.x;
+    t[0] = tot.x;
+    t[1] = tot.y;
+    t[2] = tot.z;
+    t[3] = tot.w;
+    t[4] = m;
+    t[5] = R;
+    t[6] = 0;
+    t[7] = 0;
+  }
+}
+
 __global__ __launch_bounds__(256) void index_fill_kernel(IndexParams p) {
   const int lane = threadIdx.x & 63;
   const int qb = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p.blocked) {
+    // prefixes inside the q-block's block + the totals of the blocks before it; the grand totals
+    const int num_qblocks = p.blk_tot[5];
+    const int nblk = (num_qblocks + 1023) >> 10, myblk = qb >> 10;
+    Int4 off{0, 0, 0, 0}, all{0, 0, 0, 0};
+    int maxt = 0;
+    for (int k = lane; k < nblk; k += 64) {
+      const int32_t* t = p.blk_tot + 8 * k;
+      const Int4 bt{t[0], t[1], t[2], t[3]};
+      all = all + bt;
+      if (k < myblk) off = off + bt;
+      maxt = imax(maxt, t[4]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      off = off + Int4{__shfl_xor(off.x, d, 64), __shfl_xor(off.y, d, 64), __shfl_xor(off.z, d, 64), __shfl_xor(off.w, d, 64)};
+      all = all + Int4{__shfl_xor(all.x, d, 64), __shfl_xor(all.y, d, 64), __shfl_xor(all.z, d, 64), __shfl_xor(all.w, d, 64)};
+      maxt = imax(maxt, __shfl_xor(maxt, d, 64));
+    }
+    if (qb == 0 && lane == 0) {
+      if (num_qblocks <= p.cap_qblocks) {
+        p.row_ptr[num_qblocks] = all.x;
+        p.part_ptr[num_qblocks] = all.z;
+      }
+      p.totals[0] = num_qblocks;
+      p.totals[1] = all.x;
+      p.totals[2] = all.y;
+      p.totals[3] = all.z;
+      p.totals[4] = all.w;
+      p.totals[5] = maxt;
+      p.totals[6] = 0;
+      p.totals[7] = 0;
+    }
+    if (num_qblocks > p.cap_qblocks || qb >= num_qblocks) return;
+    // (this q-block's own entries: read by this wave alone, then replaced by the prefixes over the whole index)
+    const int start = p.row_ptr[qb] + off.x, piece_prefix = p.piece_ptr[qb] + off.y, part_prefix = p.part_ptr[qb] + off.z;
+    const int split_at = p.split_pos[qb] + off.w;
+    const int b = p.qb_meta[2 * qb], r0 = p.qb_meta[2 * qb + 1];
+    const int ql = p.cu_q[b + 1] - p.cu_q[b];
+    const int n = p.seq_lens[b];
+    const int nf = p.full_lens ? imax(n, p.full_lens[b]) : n;
+    const int ctx = n - ql;
+    const int r1 = imin(r0 + p.block_m, ql);
+    const TileRanges tr = tile_ranges(effective_mode(p.mode, nf, p.tri_min_len), ctx + r0, ctx + r1 - 1, n, nf, p.si, p.sl, p.last, p.block_n, p.bn_shift);
+    const int cnt = tr.count();
+    const int pieces = imax(1, ceil_div(cnt, p.chunk));
+    fill_qblock(p, qb, b, r0, n, ctx, p.cu_q[b] + r0, tr, cnt, start, first_item_of(all.y, all.z, piece_prefix, part_prefix, pieces),
+                part_prefix, lane, 64);
+    if (lane == 0) {
+      p.row_ptr[qb] = start;
+      p.part_ptr[qb] = part_prefix;
+      if (pieces > 1 && split_at < p.cap_split) p.split_qb[split_at] = qb;
+    }
+    return;
+  }
   const int num_qblocks = p.totals[0];  // counted by index_scan_kernel earlier on this stream
   if (num_qblocks > p.cap_qblocks || qb >= num_qblocks) return;
   const int b = p.qb_meta[2 * qb], r0 = p.qb_meta[2 * qb + 1];
@@ -396,6 +554,8 @@ extern "C" int tmx_build_block_index(tmx_index_t* idx, const int32_t* cu_q_dev, 
   }
   p.seq_qb_ptr = idx->scratch;
   p.piece_ptr = idx->scratch + idx->batch + 1;
+  p.split_pos = p.piece_ptr + idx->cap_qblocks + 1;
+  p.blk_tot = p.split_pos + idx->cap_qblocks + 1;
   p.batch = idx->batch;
   p.block_m = idx->block_m;
   p.block_n = idx->block_n;
@@ -410,13 +570,17 @@ extern "C" int tmx_build_block_index(tmx_index_t* idx, const int32_t* cu_q_dev, 
   p.cap_items = (int)idx->cap_items;
   p.cap_split = (int)idx->cap_split;
   p.fused = idx->cap_qblocks <= 1024 ? 1 : 0;
+  p.blocked = p.fused ? 0 : 1;
   p.bn_shift = (idx->block_n & (idx->block_n - 1)) == 0 ? __builtin_ctz(idx->block_n) : -1;
   p.bm_shift = (idx->block_m & (idx->block_m - 1)) == 0 ? __builtin_ctz(idx->block_m) : -1;
   hipStream_t s = (hipStream_t)stream;
-  tmx::index_scan_kernel<<<1, 1024, 0, s>>>(p);
-  TMX_CHECK_HIP(hipGetLastError());
-  if (idx->cap_qblocks > 0 && !p.fused) {
-    const int nq = (int)idx->cap_qblocks;  // upper bound of the q-block count; surplus waves exit
+  if (p.fused) {
+    tmx::index_scan_kernel<<<1, 1024, 0, s>>>(p);
+    TMX_CHECK_HIP(hipGetLastError());
+  } else {
+    const int nq = (int)idx->cap_qblocks;  // upper bound of the q-block count; surplus threads / waves find nothing
+    tmx::index_block_kernel<<<tmx::ceil_div(nq, 1024), 1024, 0, s>>>(p);
+    TMX_CHECK_HIP(hipGetLastError());
     tmx::index_fill_kernel<<<tmx::ceil_div(nq, 4), 256, 0, s>>>(p);
     TMX_CHECK_HIP(hipGetLastError());
   }

@@ -59,6 +59,9 @@ void fill_index(tmx_index_t& ix, const std::vector<Tensor>& b, const std::option
   ix.totals = i32(b[6]);
   ix.scratch = i32(b[7]);
   ix.cap_qblocks = b[0].numel() - 1;
+  TORCH_CHECK(b[7].numel() >= TMX_INDEX_SCRATCH_INTS(batch, ix.cap_qblocks),
+              "trianglemix: the index's scratch tensor has ", b[7].numel(), " entries, ",
+              TMX_INDEX_SCRATCH_INTS(batch, ix.cap_qblocks), " are needed (batch + 1 + 2 (R + 1) + 8 (R / 1024 + 1))");
   ix.cap_nnz = b[1].numel();
   ix.cap_items = b[4].numel() / 8;
   ix.cap_split = b[5].numel();

@@ -246,7 +246,7 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
     off, total = {}, 0
     for name, n in (("items", 8 * n_items), ("tile_pages", 2 * nnz if block_table is not None else -1),
                     ("row_ptr", R + 1), ("col_idx", nnz), ("qb_meta", 2 * R), ("part_ptr", R + 1),
-                    ("split_qb", n_split), ("totals", 8), ("scratch", batch + 1 + 2 * (R + 1))):
+                    ("split_qb", n_split), ("totals", 8), ("scratch", batch + 1 + 2 * (R + 1) + 8 * (R // 1024 + 1))):
         if n < 0:
             continue
         off[name] = (total, n)
