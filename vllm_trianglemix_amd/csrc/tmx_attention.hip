@@ -389,6 +389,10 @@ __device__ __forceinline__ bool band_qblock(const BandRule& r, int pos0, int n, 
 #ifndef TMX_V16_LIST
 #define TMX_V16_LIST 0
 #endif
+// Partial results of split q-blocks stored with the non-temporal policy (A/B switch).
+#ifndef TMX_PARTIAL_NT
+#define TMX_PARTIAL_NT 0
+#endif
 
 // kvc: the workgroup's K/V head chunk; [qb, qb_end): its run of q-blocks.
 // FP8: K and V are an fp8 (e4m3fn) paged cache.  The wave that fetches eight rows of a half (1 KiB of fp8 bytes)
@@ -814,6 +818,9 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
         constexpr int RR = NPASS * RPP;           // rows per round (the stage holds 1 KiB)
         const int l = opaque(lane);
         const unsigned stg = lds_base + (NSLOT + 1) * HALFB + wave * 1024;  // this wave's stage (nobody else's)
+        // (rows of the stage are HROWB bytes apart: rows two apart would meet in the same LDS banks, so the 16-byte
+        // chunks of a row are XOR-swizzled by the row, on the way in and on the way out)
+        const int wsw = NPASS == 2 ? ((qi % RR) >> 1) & 3 : 0;
         const unsigned waddr = stg + (qi % RR) * HROWB + 2 * ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
         // wave-uniform base of the wave's 16 output rows + this lane's 32-bit byte offset
         char* const ob = reinterpret_cast<char*>(p.out) + 2 * orows;
@@ -842,9 +849,11 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
           for (int j = 0; j < NR; ++j) {
             if (qi / RR == j) {
 #pragma unroll
-              for (int x = 0; x < HP; ++x) *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(waddr + 64 * x) = rc[x];
+              for (int x = 0; x < HP; ++x)
+                *(__attribute__((address_space(3))) u32x4*)(uintptr_t)((waddr + 64 * x) ^ (16 * wsw)) = rc[x];
             }
-            asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(stg + 16 * l) : "memory");
+            const int rsw = NPASS == 2 ? ((l / (CPR / NPASS)) >> 1) & 3 : 0;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"((stg + 16 * l) ^ (16 * rsw)) : "memory");
           }
 #pragma unroll
           for (int j = 0; j < NR; ++j) {
@@ -1742,8 +1751,13 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         float* po = p.partial_o + prow * D + 4 * g;
         if (row_valid) {
 #pragma unroll
-          for (int db = 0; db < DB; ++db)
+          for (int db = 0; db < DB; ++db) {
+#if TMX_PARTIAL_NT
+            store_stream16(po + 16 * db, make_float4(acc[db][0], acc[db][1], acc[db][2], acc[db][3]));
+#else
             *reinterpret_cast<float4*>(po + 16 * db) = make_float4(acc[db][0], acc[db][1], acc[db][2], acc[db][3]);
+#endif
+          }
           if (g == 0) *reinterpret_cast<float2*>(p.partial_ml + prow * 2) = make_float2(m_run, l_tot);
         }
         stores = DB;  // the (max, sum) store may be skipped by lanes; counting fewer only waits longer

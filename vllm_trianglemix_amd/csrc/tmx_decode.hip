@@ -10,8 +10,11 @@
 //   Per 16 keys and wave: K rows arrive in the A layout of v_mfma_f32_16x16x32 (lane = key, 16 bytes of the
 //   row per k-step), the 4 query heads are 4 of the 16 B columns, so 4 matrix instructions give all scores;
 //   V rows arrive as 16 bytes per lane (lane group g of 16 lanes = key 4 g + i of step i, lane = 8 head-dim
-//   columns); the probabilities reach those lanes by ds_bpermute (16 per 16 keys) and the weighted sum runs on
-//   the vector units in fp32.  The next 16 keys' 8 loads per lane are in flight while a group is computed.
+//   columns).  The weighted sum runs on the matrix cores as well (the default): the V rows of 16 keys go
+//   through a 4-KiB LDS stage of the wave's own and come back transposed (ds_read_b64_tr_b16), the probabilities
+//   stay in registers as the second operand (two bf16 terms, one fp16 term).  TMX_ATTN_DECODE_VALU keeps the
+//   earlier form for comparison: the probabilities reach the V lanes by ds_bpermute (16 per 16 keys) and the sum
+//   runs on the vector units in fp32.  The next 16 keys' 8 loads per lane are in flight while a group is computed.
 //   An fp8 (e4m3fn) cache is read at half the bytes and descaled in registers: value = fp8 x scale, rounded
 //   once to the 16-bit type (vllm/v1/attention/backends/rocm_attn.py:421-422).
 //   At the end the 16 partial results of a workgroup (4 waves x 4 lane groups) merge through LDS into the
