@@ -4,6 +4,7 @@
 # usage (GPU box): CFGS="1:32 1:16 0:32" bash tools/band_exp2.sh
 [ -n "$RLS" ] && export TMX_BAND_RLS=$RLS
 [ -n "$TAU" ] && export TMX_BAND_TAU=$TAU
+[ -n "$WALK" ] && export TMX_WALK_SHIFT=$WALK
 export TRIANGLEMIX_BINDING=ctypes TMX_LIB_PATH=$PWD/tools/libtrianglemix_hip_tune.so
 for cfg in ${CFGS:-"0:32 1:32 1:16 1:8 2:32"}; do
   e=${cfg%%:*}; rl=${cfg##*:}

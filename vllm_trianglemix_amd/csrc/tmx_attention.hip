@@ -165,6 +165,7 @@ struct AttnParams {
   int n_generic;              // workgroups 0 .. n_generic - 1 walk the work list, the others are band workgroups
   int num_qblocks;            // q-blocks of the batch
   int batch, chunk_tiles;     // requests of the step; tiles per piece of a split q-block
+  int walk_shift;             // pieces of split q-blocks walk their tile list in 1 << walk_shift interleaved parts
   int dense_on;               // requests of kDenseMinRows query rows or more are computed by the dense causal kernel
   int decode_on;              // one-row requests whose row is dense are computed by the decode kernel
   int xcd_generic, xcd_band;  // workgroup -> K/V head chunk mapping that puts the chunks of a K/V head on one XCD
@@ -1133,6 +1134,18 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       if (!band_qblock(band_rule, a1.z, a1.w, nf)) return 1;
     }
   };
+  // Walk order of a piece of a split q-block (the trailing dense rows): front to back (s = 0), or in 1 << s
+  // interleaved parts -- entry e is tile (e >> s) of part (e & mask).  A piece covers the keys of consecutive band
+  // runs, which the band workgroups stream at the same time, each from its own start; walked in as many parts the
+  // piece stays within a fraction of the launch of every band run it shares keys with (an attempt to have
+  // whoever comes second find the keys in the Infinity Cache: no measurable effect, see launch_attn; s = 0 is
+  // shipped).  Online softmax does not care about the order; both sides of the kernel (fetching, arithmetic) use
+  // the same function.
+  auto walk_il = [&](const i32x4& a0) -> int {
+    const int s = p.walk_shift;
+    return (s > 0 && a0.w >= 0 && (a0.z & ((1 << s) - 1)) == 0) ? s : 0;
+  };
+  auto walk_entry = [&](int e, int cnt, int s) -> int { return (e >> s) + (cnt >> s) * (e & ((1 << s) - 1)); };
   // the item being computed and the one after it
   i32x4 ca0, ca1, cb0, cb1;
   int c_valid = fetch_item(ca0, ca1);
@@ -1143,7 +1156,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   // the next one, never further (an item shorter than the ring is deep leaves the ring less full):
   // i_src = 0 / 1 names the item the cursor is in, 2 = nothing to issue until the compute side moves on.
   int i_src = 2;
-  int i_pos = 0;    // next entry of col_idx to issue
+  int i_pos = 0;    // first entry of the cursor's item in col_idx
+  int i_e = 0;      // entries of the item issued so far
+  int i_cnt = 0;    // its tile count
+  int i_il = 0;     // its walk order: log2 of the interleaved parts (walk_entry)
   int i_left = 0;   // tiles of the cursor's item not yet issued
   int i_n = 1;      // its request: sequence length, index (block table)
   int i_b = 0;
@@ -1159,6 +1175,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
   auto cursor_to = [&](const i32x4& a0, const i32x4& a1, int src) {
     i_src = src;
     i_pos = a0.y;
+    i_e = 0;
+    i_cnt = a0.z;
+    i_il = walk_il(a0);
     i_left = a0.z;
     i_n = a1.w;
     i_b = a1.x;
@@ -1181,7 +1200,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 
   auto prefetch_desc = [&]() {
     if (i_src == 2) return;
-    const int pos = i_pos;
+    const int pos = i_pos + walk_entry(i_e, i_cnt, i_il);
     d_tile = sload(p.col_idx + pos);
     if constexpr (PAGED) {
       if (p.tile_pages != nullptr) {
@@ -1251,7 +1270,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
         }
       }
     }
-    ++i_pos;
+    ++i_e;
     --i_left;
     ++gi;
     gi_slot = (gi_slot + 1 == NS) ? 0 : gi_slot + 1;
@@ -1425,9 +1444,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
     const long long bias_base = HAS_BIAS ? (long long)ca1.x * p.bias_stride_b + (long long)head * p.bias_stride_h : 0;
 
     // tile numbers of the first group (clamped reads stay inside the item's list)
+    const int c_il = walk_il(ca0);
     int nt[kGroupMax];
 #pragma unroll
-    for (int u = 0; u < kGroupMax; ++u) nt[u] = ntiles > 0 ? sload(p.col_idx + col_start + imin(u, ntiles - 1)) : 0;
+    for (int u = 0; u < kGroupMax; ++u)
+      nt[u] = ntiles > 0 ? sload(p.col_idx + col_start + walk_entry(imin(u, ntiles - 1), ntiles, c_il)) : 0;
 
     // ---- Q fragments of this wave's 16 rows (B operand of S^T), from the wave's private region ----
     frag qf[KS];
@@ -1708,7 +1729,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       const int t_next = t + cnt;
       if (t_next < ntiles) {
 #pragma unroll
-        for (int u = 0; u < kGroupMax; ++u) nt[u] = sload(p.col_idx + col_start + imin(t_next + u, ntiles - 1));
+        for (int u = 0; u < kGroupMax; ++u)
+          nt[u] = sload(p.col_idx + col_start + walk_entry(imin(t_next + u, ntiles - 1), ntiles, c_il));
       }
 #ifdef TMX_ABLATE_COMPUTE
       const bool compute = w_has_rows && p.scale_log2 == 12345.f;
@@ -2022,6 +2044,15 @@ static int launch_attn(const AttnParams& p_in, hipStream_t s) {
       }
     }
 #endif
+    // Interleaved walk of the pieces (tuning builds, TMX_WALK_SHIFT = log2 of the parts; as many parts as band runs
+    // share a piece's keys would be 1 at 32k tokens).  Measured at 32k tokens, Qwen3-8B heads, one box, three
+    // alternating rounds: 154.3-155.5 us front to back, 155.1-156.0 in two parts, 155.0-155.3 in four -- no
+    // difference, so either the second read of K/V is not what the launch waits for or those lines do not stay in
+    // the Infinity Cache beside the query / output streams; the counters (L2 fills, which count cache hits too) cannot tell.
+    p.walk_shift = 0;
+#ifdef TMX_TUNING
+    if (const char* env = getenv("TMX_WALK_SHIFT")) p.walk_shift = atoi(env);
+#endif
     const long long total = want + runs * p.Y;
     TMX_CHECK_SUPPORTED(total < (1ll << 31), "tmx_attention: too many workgroups");
     grid = (unsigned)total;
@@ -2272,6 +2303,7 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.band_rls = 0;
   p.batch = a->batch;
   p.chunk_tiles = ix->chunk_tiles;
+  p.walk_shift = 0;
   p.n_generic = 0;
   p.exp_mode = 0;
   p.xcd_generic = p.xcd_band = 0;
