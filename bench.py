@@ -489,6 +489,21 @@ def main():
         except Exception as e:  # pragma: no cover
             extra["decode_error"] = repr(e)[:200]
 
+    if not args.no_baselines and rank == 0 and world == 1:
+        # The headline is a settled-clock figure.  A serving step after a pause sees an idle GPU's clocks: one
+        # step, timed by events, after 200 ms without work (median of 5).
+        cold = []
+        for _ in range(5):
+            torch.cuda.synchronize(dev)
+            time.sleep(0.2)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            step()
+            eb.record()
+            torch.cuda.synchronize(dev)
+            cold.append(ea.elapsed_time(eb))
+        extra["step_after_200ms_idle_ms"] = float(np.median(cold))
+
     if args.oproj:
         hidden = cfg["hidden"]
         w = (torch.randn((hidden, H * D), device=dev) * 0.02).bfloat16()
