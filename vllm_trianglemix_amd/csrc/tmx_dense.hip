@@ -24,6 +24,8 @@
 #include "tmx_common.h"
 #include "tmx_dense.h"
 
+#include <type_traits>
+
 namespace tmx {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -39,6 +41,7 @@ constexpr int kDN = 64;        // keys per tile
 constexpr int kDRowB = 256;    // bytes per K / V row in LDS (head size 128, 16-bit)
 constexpr int kDTile = kDN * kDRowB;  // one tensor of one tile: 16 KB
 constexpr float kDMinusBig = -1.0e30f;
+constexpr int kQkAhead = 4;  // K fragments in flight in the first product (at most 4: the wait counts are written out)
 constexpr float kDSlack = 8.0f;  // the running maximum moves only when a tile exceeds it by more than this (log2 units)
 
 template <typename T>
@@ -68,7 +71,16 @@ __device__ __forceinline__ uint32_t bf16x2_to_f16x2(uint32_t w) {
 }
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 __device__ __forceinline__ uint4 lds_b128(unsigned addr) {
+  __builtin_assume((addr & 15u) == 0);  // (lets a register + immediate address keep the 16-byte form)
   return __builtin_bit_cast(uint4, *(const __attribute__((address_space(3))) u32x4_t*)(uintptr_t)addr);
+}
+// 16 bytes from LDS at a per-lane address plus a compile-time offset, by an instruction the compiler neither reorders
+// nor waits for: the caller counts it in lgkmcnt itself.  (Written out because the compiler turns a 16-byte read at
+// register + immediate into two 8-byte ones at half the rate.)
+template <unsigned OFF>
+__device__ __forceinline__ void lds_b128_at(int addr, u32x4_t& dst) {
+  static_assert(OFF < 65536, "the offset field has 16 bits");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void lds_store_b128(unsigned addr, uint4 v) {
   *(__attribute__((address_space(3))) u32x4_t*)(uintptr_t)addr = __builtin_bit_cast(u32x4_t, v);
@@ -93,6 +105,7 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
   const int r = lane & 31, h = lane >> 5;
   const int hg = wave & 3, rb = wave >> 2;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds));
+  __builtin_assume((lds_base & 1023u) == 0);  // (the array's alignment, lost through the scalar copy)
 
   // ---- the step's cache write, fused (16-bit cache; the launch reads the step's keys from k_new / v_new) ----
   if constexpr (PAGED && !KV8) {
@@ -142,26 +155,33 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
   const int head = kvh * p.G + (kvc - kvh * chunks) * 4 + hg;
 
   // ---- per-lane constants ----
+  // (All LDS addresses below are a per-lane register that already holds the LDS base, plus a compile-time offset: the
+  // tile loop is unrolled over its two buffers so that no read or write needs an address computation.)
   // K fragment (A of S^T = K Q^T): key row 32 kb + r, 16-byte chunk 2 ks + h, stored at chunk ^ (row & 15)
   int koff[8];
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) koff[ks] = r * kDRowB + 16 * ((2 * ks + h) ^ (r & 15));
+  for (int ks = 0; ks < 8; ++ks) koff[ks] = (int)lds_base + r * kDRowB + 16 * ((2 * ks + h) ^ (r & 15));
   // V^T fragment (A of O^T = V^T P^T): two transposed 4-key x 16-column blocks; lane 4 q + pp of a 16-lane group
   // addresses key row q of the block, columns 4 pp .. 4 pp + 3 of the group's 16; chunk index ^ ((key & 3) << 2)
   const int tq = (lane & 15) >> 2, tpp = lane & 3, dhalf = (lane >> 4) & 1;
   int voff[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db)
-    voff[db] = kDTile + (4 * h + tq) * kDRowB + 16 * ((((db ^ tq) << 2)) | (2 * dhalf + (tpp >> 1))) + 8 * (tpp & 1);
+    voff[db] = (int)lds_base + kDTile + (4 * h + tq) * kDRowB + 16 * ((((db ^ tq) << 2)) | (2 * dhalf + (tpp >> 1))) + 8 * (tpp & 1);
   // staging: thread t carries 32 bytes (chunks 2 c2, 2 c2 + 1) of key row t / 8 of K and of V
   const int srow = tid >> 3, sc2 = tid & 7;
-  const unsigned st_k0 = srow * kDRowB + 16 * ((2 * sc2) ^ (srow & 15));
-  const unsigned st_k1 = srow * kDRowB + 16 * ((2 * sc2 + 1) ^ (srow & 15));
-  const unsigned st_v0 = kDTile + srow * kDRowB + 16 * ((2 * sc2) ^ ((srow & 3) << 2));
-  const unsigned st_v1 = kDTile + srow * kDRowB + 16 * ((2 * sc2 + 1) ^ ((srow & 3) << 2));
+  const unsigned st_k0 = lds_base + srow * kDRowB + 16 * ((2 * sc2) ^ (srow & 15));
+  const unsigned st_k1 = lds_base + srow * kDRowB + 16 * ((2 * sc2 + 1) ^ (srow & 15));
+  const unsigned st_v0 = lds_base + kDTile + srow * kDRowB + 16 * ((2 * sc2) ^ ((srow & 3) << 2));
+  const unsigned st_v1 = lds_base + kDTile + srow * kDRowB + 16 * ((2 * sc2 + 1) ^ ((srow & 3) << 2));
   const int kv_row_bytes = KVB * p.kv_stride_t;
   const char* const k_head = reinterpret_cast<const char*>(p.k) + (long long)KVB * kvh * p.kv_stride_h + 16 * KVB * sc2;
   const char* const v_head = reinterpret_cast<const char*>(p.v) + (long long)KVB * kvh * p.kv_stride_h + 16 * KVB * sc2;
+  // the same without the lane's column: wave-uniform bases of the cache-only fetch (scalar base + 32-bit lane offset)
+  const char* const k_head_s = reinterpret_cast<const char*>(p.k) + (long long)KVB * kvh * p.kv_stride_h;
+  const char* const v_head_s = reinterpret_cast<const char*>(p.v) + (long long)KVB * kvh * p.kv_stride_h;
+  bool two_sources = false;  // some keys of the launch are rows of the step's own tensors
+  if constexpr (PAGED && !KV8) two_sources = p.k_new != nullptr;
 
   const int rounds = (num_blocks + lanes_per_unit - 1) / lanes_per_unit;
 #pragma unroll 1
@@ -205,13 +225,34 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
 
     const long long krow0 = PAGED ? 0 : (long long)dsload(p.cu_k + b);
     const int32_t* const bt = PAGED ? p.block_table + (long long)b * p.block_table_stride : nullptr;
-    // this thread's 32 bytes of K and of V of tile t (keys past the end read the last key: masked later)
-    auto fetch = [&](int t, uint4 (&kreg)[2], uint4 (&vreg)[2]) {
-      const int key_w = imin(kDN * t + 8 * wave, n - 1);     // the wave's first key (its 8 keys share a page)
+    // physical page of the wave's keys in tile t (its 8 keys share a page); looked up a tile before it is used, so
+    // that no fetch waits for the lookup (any t: the key is clamped to the sequence)
+    auto page_of = [&](int t) -> int {
+      if constexpr (PAGED) return dsload(bt + (imin(kDN * t + 8 * wave, n - 1) >> p.page_shift));
+      return 0;
+    };
+    // this thread's 32 bytes of K and of V of tile t, `page` = page_of(t) (keys past the end read the last key:
+    // masked later)
+    auto fetch = [&](int t, int page, uint4 (&kreg)[2], uint4 (&vreg)[2]) {
       const int key = imin(kDN * t + srow, n - 1);
+      if constexpr (PAGED) {
+        if (!two_sources) {
+          const long long base = (long long)KVB * page * p.kv_stride_page;  // wave-uniform
+          const unsigned lane_off = (unsigned)((key & (p.page_size - 1)) * kv_row_bytes + 16 * KVB * sc2);
+          const char* ksrc = k_head_s + base;
+          const char* vsrc = v_head_s + base;
+          kreg[0] = *reinterpret_cast<const uint4*>(ksrc + lane_off);
+          vreg[0] = *reinterpret_cast<const uint4*>(vsrc + lane_off);
+          if constexpr (!KV8) {
+            kreg[1] = *reinterpret_cast<const uint4*>(ksrc + lane_off + 16);
+            vreg[1] = *reinterpret_cast<const uint4*>(vsrc + lane_off + 16);
+          }
+          return;
+        }
+      }
       long long off;
       if constexpr (PAGED) {
-        const long long pg = dsload(bt + (key_w >> p.page_shift));
+        const long long pg = page;
         off = (long long)KVB * pg * p.kv_stride_page + (long long)(key & (p.page_size - 1)) * kv_row_bytes;
       } else {
         off = (krow0 + key) * kv_row_bytes;
@@ -286,28 +327,48 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
     __syncthreads();
     {
       uint4 kreg[2], vreg[2];
-      fetch(0, kreg, vreg);
-      stage(lds_base, kreg, vreg);
+      fetch(0, page_of(0), kreg, vreg);
+      stage(0u, kreg, vreg);
     }
+    int page_next = page_of(1);
     __syncthreads();
 
-#pragma unroll 1
-    for (int t = 0; t < num_tiles; ++t) {
-      const unsigned cur = lds_base + (unsigned)(t & 1) * 2 * kDTile;
-      const unsigned nxt = lds_base + (unsigned)((t + 1) & 1) * 2 * kDTile;
+    auto tile = [&](int t, auto buffer) {
+      constexpr unsigned cur = decltype(buffer)::value * 2 * kDTile;
+      constexpr unsigned nxt = (1 - decltype(buffer)::value) * 2 * kDTile;
       uint4 kreg[2], vreg[2];
       const bool more = t + 1 < num_tiles;
-      if (more) fetch(t + 1, kreg, vreg);
+      if (more) fetch(t + 1, page_next, kreg, vreg);
+      page_next = page_of(t + 2);
 
       if (t < w_tiles) {
         // ---- S^T = K Q^T: two 32-key blocks ----
         f32x16 s[2];
+        // The K fragments of kQkAhead steps are in flight at a time, read by instructions the compiler cannot reorder
+        // (register + immediate offset: no address arithmetic) and waited for by count: left to itself it reads one
+        // fragment, waits for it and multiplies, sixteen times over.
+        {
+          f32x16 zero;  // (a constant operand of each block's first instruction: no registers are cleared)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+          for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+          u32x4_t kf[kQkAhead];
+          auto rd = [&](int i, u32x4_t& dst) {
+            if (i < 8) lds_b128_at<cur>(koff[i & 7], dst);
+            else lds_b128_at<cur + 32 * kDRowB>(koff[i & 7], dst);
+          };
 #pragma unroll
-          for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+          for (int i = 0; i < kQkAhead; ++i) rd(i, kf[i]);
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks) s[kb] = mfma_qk<BF16>(lds_b128(cur + koff[ks] + kb * 32 * kDRowB), qf[ks], s[kb]);
+          for (int i = 0; i < 16; ++i) {
+            u32x4_t& f = kf[i % kQkAhead];
+            const int left = 15 - i < kQkAhead - 1 ? 15 - i : kQkAhead - 1;  // reads that may stay in flight
+            if (left == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f)::"memory");
+            else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f)::"memory");
+            else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f)::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f)::"memory");
+            s[i >> 3] = mfma_qk<BF16>(__builtin_bit_cast(uint4, f), qf[i & 7], (i & 7) == 0 ? zero : s[i >> 3]);
+            if (i + kQkAhead < 16) rd(i + kQkAhead, f);
+          }
         }
         // register i of block kb is key 64 t + 32 kb + (i & 3) + 8 (i >> 2) + 4 h
         const int key0 = kDN * t + 4 * h;
@@ -375,6 +436,11 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
 
       if (more) stage(nxt, kreg, vreg);
       __syncthreads();
+    };
+#pragma unroll 1
+    for (int t = 0; t < num_tiles; t += 2) {
+      tile(t, std::integral_constant<int, 0>{});
+      if (t + 1 < num_tiles) tile(t + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue: lane (row r, half h) holds columns 32 db + 8 e + 4 h .. + 3 in registers 4 e .. 4 e + 3 of acc[db] ----
