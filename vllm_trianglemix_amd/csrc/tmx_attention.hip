@@ -237,6 +237,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // Running maximum before any key was seen: finite, so that exp2(m_old - m_new) and exp2(-inf - m)
 // need no special cases (scores are finite; a fully masked row still ends with sum 0 -> NaN).
+// 0: the compiler keeps the band workgroups' sixteen mask comparisons as lane masks in scalar registers (and brings
+// them back through v_readlane, two per selection).  1: compared and selected in the loop -- 44 fewer spilled scalar
+// registers, but the three thresholds then live in vector registers the loop does not have (4 spilled): measured
+// 163 us against 160 for the launch, so off.
+#ifndef TMX_BAND_MASKS_IN_LOOP
+#define TMX_BAND_MASKS_IN_LOOP 0
+#endif
 constexpr float kMinusBig = -1.0e30f;
 
 // Workgroup shape of the attention kernel: 4 (head, 32-row) slots x 2 sixteen-row blocks = 8 waves
@@ -471,7 +478,7 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
   // starts 32 keys below the wave's first row, B 16 below, C at it: distance row - key = qi + {32, 16, 0} - key.
   // sink group: key <= si; A: row - key = qi + 32 - key <= sl; B: qi + 16 - key <= sl; C: key <= qi.  In terms
   // of the lane's element c (key = 4 g + c): c <= c_sink, c >= c_win (A), c >= c_win - 16 (B), c <= c_diag.
-  const int c_sink = p.si - 4 * g, c_win = qi + 32 - p.sl - 4 * g, c_diag = qi - 4 * g;
+  int c_sink = p.si - 4 * g, c_win = qi + 32 - p.sl - 4 * g, c_diag = qi - 4 * g;  // (never changed: see the masks)
   const float mult = p.scale_log2;
   // query rows and output rows: wave-uniform base of the wave's 16 rows + this lane's 32-bit offset
   const char* const q_head = reinterpret_cast<const char*>(p.q) + 2ll * head * p.q_stride_h;
@@ -715,12 +722,17 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
 
       // ---- one softmax step over the 16 scores of the lane's row ----
       const float ninf = -__builtin_inff();
+#if TMX_BAND_MASKS_IN_LOOP
+      // (the thresholds are hidden from the compiler here, so that it cannot move the comparisons out of the loop)
+      asm volatile("" : "+v"(c_sink), "+v"(c_win), "+v"(c_diag));
+#endif
+      const int cs = c_sink, cw = c_win, cd = c_diag;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        sc[0][c] = c <= c_sink ? sc[0][c] : ninf;
-        sc[1][c] = c >= c_win ? sc[1][c] : ninf;
-        sc[2][c] = c >= c_win - 16 ? sc[2][c] : ninf;
-        sc[3][c] = c <= c_diag ? sc[3][c] : ninf;
+        sc[0][c] = c <= cs ? sc[0][c] : ninf;
+        sc[1][c] = c >= cw ? sc[1][c] : ninf;
+        sc[2][c] = c >= cw - 16 ? sc[2][c] : ninf;
+        sc[3][c] = c <= cd ? sc[3][c] : ninf;
       }
       float tmax = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
                          fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
