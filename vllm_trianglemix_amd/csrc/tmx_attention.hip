@@ -1875,8 +1875,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 }
 
 // Merge the pieces of every split q-block: out = sum_p O_p 2^(m_p - M) / sum_p l_p 2^(m_p - M).
-// One workgroup per (split q-block, head, 8 rows): a thread owns 4 output columns of one row and
-// folds the pieces in with a running maximum, 4 pieces' loads in flight at a time.
+// One workgroup per (split q-block, head, 8 rows): a thread owns 4 output columns of one row.  The pass is a chain
+// of dependent trips to memory, so it is kept short: the (max, sum) pairs AND the partial rows of up to 16 pieces
+// are asked for in one go, together with the request's bounds (the partial buffers hold block_m rows per slot, so
+// the loads need no bounds; only the store does); more than 16 pieces fold in by rounds with a running maximum.
 template <typename TR, int D>
 __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p) {
   constexpr int C4 = D / 4;
@@ -1887,21 +1889,15 @@ __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p
   const int head = blockIdx.y;
   const int slot0 = p.part_ptr[qb], np = p.part_ptr[qb + 1] - slot0;
   const int b = p.qb_meta[2 * qb], row0 = p.qb_meta[2 * qb + 1];
-  const int q_start = p.cu_q[b];
-  const int q_len = p.cu_q[b + 1] - q_start;
-  if (row >= imin(p.block_m, q_len - row0)) return;
-  if (p.dense_on && q_len >= kDenseMinRows) return;  // the dense causal kernel wrote this request's rows
+  if (row >= p.block_m) return;
   const long long stride = (long long)p.H * p.block_m;  // partial rows between consecutive pieces
   const long long prow0 = ((long long)slot0 * p.H + head) * p.block_m + row;
-  // pass 1 over the (max, sum) pairs: the common maximum; pass 2: weights, independent loads
   const float2* mlp = reinterpret_cast<const float2*>(p.partial_ml) + prow0;
-  float M = kMinusBig;
-  for (int pc = 0; pc < np; ++pc) M = fmaxf(M, mlp[(long long)pc * stride].x);
-  float l = 0.f;
-  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* op = reinterpret_cast<const float4*>(p.partial_o + prow0 * D) + d4;
   const long long ostride = stride * C4;  // float4 elements between consecutive pieces
-  constexpr int UN = 8;
+  float M = kMinusBig, l = 0.f;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int UN = 16;
   for (int pc = 0; pc < np; pc += UN) {
     float2 ml[UN];
     float4 v[UN];
@@ -1911,6 +1907,18 @@ __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p
       ml[u] = mlp[(long long)q * stride];
       v[u] = __builtin_bit_cast(float4, __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(op + (long long)q * ostride)));  // read once
     }
+    float Mr = M;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) Mr = fmaxf(Mr, ml[u].x);  // (a repeated last piece changes nothing)
+    if (pc > 0) {  // later rounds: bring what is summed so far to the new maximum
+      const float alpha = __builtin_amdgcn_exp2f(M - Mr);
+      l *= alpha;
+      o.x *= alpha;
+      o.y *= alpha;
+      o.z *= alpha;
+      o.w *= alpha;
+    }
+    M = Mr;
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const float w = (pc + u < np) ? __builtin_amdgcn_exp2f(ml[u].x - M) : 0.f;
@@ -1921,6 +1929,10 @@ __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p
       o.w += w * v[u].w;
     }
   }
+  const int q_start = p.cu_q[b];
+  const int q_len = p.cu_q[b + 1] - q_start;
+  if (row >= q_len - row0) return;
+  if (p.dense_on && q_len >= kDenseMinRows) return;  // the dense causal kernel wrote this request's rows
   const float inv = 1.0f / l;  // every piece empty for this row: 0 * inf = NaN, as for an unsplit row
   o.x *= inv;
   o.y *= inv;
