@@ -431,13 +431,14 @@ def test_attention_decode_heavy_batch():
 
 
 def test_attention_split_and_combine_long():
-    """One long prompt: trailing rows are split into many pieces and merged."""
+    """One long prompt: trailing rows are split into many pieces and merged (130 tiles per row: 44 / 17 / 3 / 1 pieces;
+    the merge pass takes 16 pieces per round, so the first two cases go through its running maximum)."""
     ops = _ops()
     n, H, Hkv, D = 4096 + 37, 8, 2, 128
     q, ks, vs = _rand_case(77, [n], [n], H, Hkv, D)
     scale = D ** -0.5
     ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], [0, n], [n], scale, "triangle", 4, 32, 64)
-    for chunk in (8, 64, 1000):
+    for chunk in (3, 8, 64, 1000):
         got = _run_varlen(ops, q, ks, vs, [n], [n], scale, "triangle", (4, 32, 64), paged=True, chunk=chunk)
         print(f"split/combine chunk {chunk}: max abs err {np.abs(got - ref).max():.2e}")
         assert np.abs(got - ref).max() <= ATOL_F32_OUT, chunk
