@@ -241,6 +241,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // them back through v_readlane, two per selection).  1: compared and selected in the loop -- 44 fewer spilled scalar
 // registers, but the three thresholds then live in vector registers the loop does not have (4 spilled): measured
 // 163 us against 160 for the launch, so off.
+#ifndef TMX_LIST_PRIO
+#define TMX_LIST_PRIO 0  // wave priority of the work-list workgroups in a launch that has band workgroups (1, 3: no effect measured)
+#endif
+#ifndef TMX_BAND_PRIO
+#define TMX_BAND_PRIO 0  // wave priority of the band workgroups (0: as the work-list workgroups; 1, 3: the work list starves, 184 us against 161)
+#endif
 #ifndef TMX_BAND_MASKS_IN_LOOP
 #define TMX_BAND_MASKS_IN_LOOP 0
 #endif
@@ -1021,10 +1027,19 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 #endif
       const UnitLane bl = unit_of(bid - ngrid, p.Y, p.Hkv, p.G / p.Gw, p.xcd_band);
       const int qb0 = bl.lane * p.band_rl;
+#if TMX_BAND_PRIO
+      // the band workgroups are the last to finish: their waves go first where a SIMD has to choose
+      __builtin_amdgcn_s_setprio(TMX_BAND_PRIO);
+#endif
       band_body<TR, D, PAGED, FP8>(p, lds_base, bl.kvc, qb0, imin(p.band_tail0, qb0 + p.band_rl), true);
       return;
     }
   }
+#if TMX_LIST_PRIO
+  // a work-list tile step is a chain (scalar walk, fetch, barrier, matrix instructions) on which eight waves wait;
+  // the band waves beside it mostly wait for memory
+  if (p.band_on) __builtin_amdgcn_s_setprio(TMX_LIST_PRIO);
+#endif
 #ifdef TMX_TUNING
   if (p.exp_mode & 1) return;
 #endif
