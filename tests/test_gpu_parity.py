@@ -1209,6 +1209,8 @@ def test_band_path_matches_oracle_and_work_list(case):
     dict(q=[513, 130], s=[1999, 130], H=16, Hkv=2, paged=True, page=64, dtype=torch.float16),  # 8 heads per K/V head
     dict(q=[1100], s=[1100], H=4, Hkv=1, out=torch.bfloat16),
     dict(q=[200, 333], s=[200, 1333], H=4, Hkv=4, out=torch.float16, dtype=torch.float16),  # no grouping: work list only
+    # 1 to 5 key tiles per 64-row block, odd and even counts (the tile loop is unrolled over its two LDS buffers)
+    dict(q=[17, 64, 65, 128, 129, 192, 193], s=[67, 64, 128, 129, 129, 192, 300], H=8, Hkv=2, paged=True),
 ])
 def test_dense_causal_kernel_matches_oracle_and_work_list(case):
     """Causal launches (the layers outside the triangle set): requests with 17 query rows or more run on the
