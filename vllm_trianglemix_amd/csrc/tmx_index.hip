@@ -22,6 +22,13 @@
 // 16 blocks side by side instead of 16 rounds on one workgroup).
 #include "tmx_common.h"
 
+#ifdef TMX_INDEX_STAMPS
+__device__ long long g_idx_stamps[16];
+extern "C" int tmx_index_read_stamps(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_idx_stamps), sizeof(long long) * 16); }
+#define ISTAMP(i) do { if (threadIdx.x == 0) g_idx_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ISTAMP(i)
+#endif
 namespace tmx {
 
 struct Int4 {
@@ -31,21 +38,25 @@ __device__ __forceinline__ Int4 operator+(const Int4& a, const Int4& b) {
   return Int4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
 }
 
-__device__ __forceinline__ Int4 shfl_up4(const Int4& v, int delta) {
-  return Int4{__shfl_up(v.x, delta, 64), __shfl_up(v.y, delta, 64), __shfl_up(v.z, delta, 64),
-              __shfl_up(v.w, delta, 64)};
+// Inclusive scan over the 64 lanes of a wave by data-parallel-primitive moves (no LDS, no lane arithmetic): four
+// shifts inside each row of 16 lanes (lanes without a source read 0), then the last lane of rows 0 and 2 is added to
+// rows 1 and 3, then lane 31 to lanes 32..63.  (Through __shfl_up, which goes through the LDS crossbar with an address
+// per lane, the two scans of the index build took 6,000 cycles each with 16 waves at it.)
+__device__ __forceinline__ int wave_inclusive_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  return x;
 }
 
 // Exclusive scan of one Int4 per thread over a 1024-thread workgroup.
 // Returns the exclusive prefix; `total` receives the workgroup sum.
 __device__ Int4 block_exclusive_scan(Int4 v, Int4* wave_sums /* LDS [16] */, Int4& total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  Int4 inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    Int4 o = shfl_up4(inc, d);
-    if (lane >= d) inc = inc + o;
-  }
+  const Int4 inc{wave_inclusive_scan(v.x), wave_inclusive_scan(v.y), wave_inclusive_scan(v.z), wave_inclusive_scan(v.w)};
   if (lane == 63) wave_sums[wave] = inc;
   __syncthreads();
   Int4 base{0, 0, 0, 0};
@@ -168,6 +179,7 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
   const bool cached = p.batch <= 1024;
   const int tid = threadIdx.x;
   if (tid == 0) s_num_long = 0;
+  ISTAMP(0);
 
   // (a) q-blocks per request -> seq_qb_ptr
   int carry = 0;
@@ -197,6 +209,7 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
     s_num_qblocks = carry;
   }
   __syncthreads();
+  ISTAMP(1);
   const int R = s_num_qblocks;
   // request b: (first query row, query rows, keys, full length)
   auto request = [&](int b) -> int4 {
@@ -231,9 +244,11 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
       v = Int4{cnt, pieces, pieces > 1 ? pieces : 0, pieces > 1 ? 1 : 0};
       max_tiles = imax(max_tiles, cnt);
     }
+    ISTAMP(7);
     Int4 tot;
     Int4 e = block_exclusive_scan(v, wave_sums, tot);
     e = e + run;
+    ISTAMP(8);
     if (qb < R && qb < p.cap_qblocks) {
       p.row_ptr[qb] = e.x;
       p.piece_ptr[qb] = e.y;
@@ -243,6 +258,7 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
       if (v.w && e.w < p.cap_split) p.split_qb[e.w] = qb;
     }
     run = run + tot;
+    ISTAMP(9);
     if (p.fused && R <= 1024) {
       // single round: run holds the totals, this thread still holds its q-block's numbers
       bool is_long = false;
@@ -266,6 +282,7 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
         }
       }
       __syncthreads();
+      ISTAMP(3);
       const int num_long = s_num_long;
       for (int k = 0; k < imin(num_long, 64); ++k) {
         const int lq = s_long[k][0], lb = s_long[k][1], lr0 = s_long[k][2];
@@ -300,11 +317,13 @@ __global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
   }
   // workgroup max of max_tiles (reuse the scan scratch)
   __syncthreads();
+  ISTAMP(5);
   int m = max_tiles;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = imax(m, __shfl_xor(m, d, 64));
   if ((tid & 63) == 0) wave_sums[tid >> 6].x = m;
   __syncthreads();
+  ISTAMP(6);
   if (tid == 0) {
     for (int w = 1; w < 16; ++w) m = imax(m, wave_sums[w].x);
     if (R <= p.cap_qblocks) {
