@@ -505,6 +505,14 @@ int launch_dense_causal(const DenseParams& p, bool bf16, bool paged, hipStream_t
     TMX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (dev >= 0 && dev < 64) cus_cache[dev] = (unsigned)cus;
   }
+  if (paged) {
+    // (the cache-only fetch adds a 32-bit lane offset, row inside the page x row pitch, to a wave-uniform base)
+    const long long span = (long long)(p.page_size - 1) * (p.kv_fp8 ? 1 : 2) * p.kv_stride_t + 256;
+    if (span >= (1ll << 31)) {
+      set_error("dense causal kernel: a page of the K/V cache spans %lld bytes (2 GiB or more)", span);
+      return TMX_ERR_UNSUPPORTED;
+    }
+  }
   // one workgroup per CU (the registers of 8 waves x 256 fill a CU), a multiple of the K/V head chunks, and no
   // more workgroups than there are (64-row block, chunk) units at most
   long long grid = cus - cus % p.Y;
