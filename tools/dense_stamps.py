@@ -1,5 +1,5 @@
-"""Reads the cycle stamps of a dense kernel built with -DTMX_DENSE_STAMPS after one 32k launch (the stamped kernel is the
-slotted variant on branch exp/dense-slots; the shipped kernel carries no stamps)."""
+"""Reads the cycle stamps of a dense kernel built with -DTMX_DENSE_STAMPS after one 32k launch (the stamped kernel is an
+experimental slotted variant of the dense kernel; the shipped kernel carries no stamps and does not export the reader)."""
 import ctypes
 import os
 import sys
