@@ -15,8 +15,9 @@ environment) or, when `--gpus N` is given without them, from this script
 itself: it starts N copies of itself BEFORE touching any GPU, relays rank 0's
 line and exits non-zero unless all N ranks finish.  The attention needs no
 collective; the output projection's all-reduce (the only exchange step of the
-layer) is timed separately with --oproj and reported beside the main value,
-never inside it.
+layer) is timed on every run with more than one rank (and with --oproj on one)
+and reported beside the main value (extra.oproj_gemm_allreduce_ms,
+extra.layer_ms_with_oproj), never inside it.
 
 --model picks the head shape: 8b (32/8 heads, 32k), 32b (64/8 heads, 32k: 16/2
 per GPU at --gpus 4), 72b-fp8 (64/8 heads, fp8 e4m3 K/V cache, 64k: 8/1 per GPU
@@ -163,22 +164,58 @@ def free_port():
         return sk.getsockname()[1]
 
 
+def visible_gpu_count():
+    """GPUs a child process will see, found WITHOUT any HIP / HSA call (the launcher must stay GPU-free: it goes on
+    to start one process per GPU).  The visibility variables win when set; otherwise the kernel driver's topology
+    is read (/sys/class/kfd: one node per agent, GPUs are the nodes with SIMDs).  None: unknown (no such files) --
+    the ranks then find out themselves and a rank without a device fails the job."""
+    counts = []
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        if var in os.environ:
+            counts.append(len([x for x in os.environ[var].split(",") if x.strip()]))
+    if counts:
+        return min(counts)
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        found = 0
+        for d in os.listdir(nodes):
+            try:
+                with open(os.path.join(nodes, d, "properties")) as f:
+                    props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                found += 1
+        return found
+    except (OSError, ValueError):
+        return None
+
+
 def launch_ranks(args):
     """`--gpus N` without a launcher: start N copies of this script, one rank per GPU, BEFORE anything here
     has touched a GPU (this process never does: it only relays rank 0's line).  Returns the exit code:
-    non-zero unless all N ranks ran to the end and rank 0 printed a line for N GPUs."""
+    non-zero unless all N ranks ran to the end and rank 0 printed a line for N GPUs.  Every rank's stderr goes
+    to a file of its own; when a rank fails, the end of ITS stderr is shown."""
+    import tempfile
     n = args.gpus
-    if not args.dry_run and torch.cuda.device_count() < n:  # counting devices does not initialise them
-        print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} HIP device(s) are visible", file=sys.stderr)
+    seen = None if args.dry_run else visible_gpu_count()
+    if seen is not None and seen < n:
+        print(f"bench.py: --gpus {n} but only {seen} HIP device(s) are visible", file=sys.stderr)
         return 2
     port = free_port()
-    procs = []
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        errs.append(tempfile.TemporaryFile(mode="w+", prefix=f"bench_rank{r}_"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[r], text=True))
+
+    def stderr_tail(r, lines=25):
+        errs[r].seek(0)
+        return "".join(errs[r].readlines()[-lines:])
+
     failed = None
     while failed is None and any(p.poll() is None for p in procs):
         for r, p in enumerate(procs):
@@ -191,7 +228,14 @@ def launch_ranks(args):
         for p in procs:  # the exact processes started above, nothing else
             if p.poll() is None:
                 p.kill()
-        print(f"bench.py: rank {failed} of {n} exited with {procs[failed].returncode}; no result", file=sys.stderr)
+        for p in procs:
+            p.wait()
+        print(f"bench.py: rank {failed} of {n} exited with {procs[failed].returncode}; no result.  Its stderr ends:\n"
+              f"{stderr_tail(failed)}", file=sys.stderr)
+        others = [r for r, p in enumerate(procs) if r != failed and p.returncode not in (0, -9)]
+        if others:
+            print(f"bench.py: ranks {others} failed as well (rank {others[0]}'s stderr ends:\n{stderr_tail(others[0], 8)})",
+                  file=sys.stderr)
         return 1
     out = procs[0].stdout.read()
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
@@ -220,13 +264,35 @@ def dry_run(args, cfg, n, world, rank):
                                     num_cus=256)
     sz = ops.index_sizes(cu_h, sl_h, *PATTERN, bm, bn, ops.MODES["triangle"], chunk_tiles=chunk)
     t = torch.tensor([float(sz.num_items * ops.units_per_item(H, Hkv)), float(H), float(Hkv)], dtype=torch.float64)
+    extra = {}
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
+        # the layer's exchange step on host tensors over gloo, at a toy size: the row-parallel output projection with
+        # its chunked all-reduce (the path the measured run takes on the GPUs over RCCL), checked against the sum of
+        # every rank's product formed locally
+        from vllm_trianglemix_amd.parallel import RowParallelOutputProjection
+        D, hidden, toks = cfg["head_dim"], 64, 200
+        def part(r):
+            g = torch.Generator().manual_seed(100 + r)
+            return torch.randn((toks, H, D), generator=g), torch.randn((hidden, H * D), generator=g) * 0.05
+        x, w = part(rank)
+        proj = RowParallelOutputProjection(w, chunk_tokens=64)
+        t0 = time.perf_counter()
+        y = proj(x)
+        dt = time.perf_counter() - t0
+        want = sum(xr.reshape(toks, -1) @ wr.t() for xr, wr in (part(r) for r in range(world)))
+        ok = torch.tensor([1.0 if torch.allclose(y, want, rtol=1e-4, atol=1e-4) else 0.0], dtype=torch.float64)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() != 1.0:
+            raise SystemExit("bench.py --dry-run: the chunked o_proj all-reduce does not equal the sum of the ranks' products")
+        extra = {"oproj_gemm_allreduce_ms": dt * 1e3, "layer_ms_with_oproj": None,
+                 "oproj": {"tokens": toks, "hidden": hidden, "chunk_tokens": 64, "backend": "gloo (dry run, toy size)",
+                           "allreduce_bytes": toks * hidden * 4}}
     if rank == 0:
         print(json.dumps({"metric": metric_name(cfg, n), "value": None, "unit": "tokens/s", "n_gpus": world, "steps": 0,
                           "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "dry_run": True,
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "dry_run": True, "extra": extra,
                           "config": {"workload": workload_name(cfg, n), "global_batch": batch, "seq_len": n,
                                      "heads_per_gpu": int(t[1]), "kv_heads_per_gpu": int(t[2]),
                                      "head_dim": cfg["head_dim"], "parallelism": f"tp{world} (heads)",
@@ -346,6 +412,39 @@ def main():
     tokens_per_step = batch * n  # whole job: every prompt is processed once per step (heads are split over ranks)
     value = tokens_per_step / (elapsed / args.steps)
 
+    # ---- the layer's only exchange step: row-parallel o_proj GEMM + all-reduce of its partial products over the
+    # ranks (linear.py:1358-1359; RCCL over xGMI), chunked over tokens so that a chunk's all-reduce runs beside the
+    # next chunk's GEMM.  Always timed when there is more than one rank (every rank takes part), reported beside
+    # the attention-only `value`, never inside it.
+    extra = {}
+    if world > 1 or args.oproj:
+        hidden = cfg["hidden"]
+        w = (torch.randn((hidden, H * D), device=dev) * 0.02).bfloat16()
+        chunk_tokens = 8192
+        proj = RowParallelOutputProjection(w, chunk_tokens=chunk_tokens if world > 1 else 0)
+        for _ in range(2):
+            y = proj(out)
+        sync_all()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = proj(out)
+        sync_all()
+        t_op = (time.perf_counter() - t0) / reps
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([t_op], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_op = float(tt.item())
+        extra["oproj_gemm_allreduce_ms"] = t_op * 1e3
+        # (serial sum: the attention of a layer is followed by its projection; no overlap between the two is assumed)
+        extra["layer_ms_with_oproj"] = ms_per_step + t_op * 1e3
+        extra["oproj"] = {"tokens": int(out.shape[0]), "hidden": hidden, "chunk_tokens": chunk_tokens if world > 1 else 0,
+                          "backend": "nccl (RCCL)" if world > 1 else "none (one rank: GEMM only)",
+                          "allreduce_bytes": int(out.shape[0]) * hidden * 2 if world > 1 else 0,
+                          "gemm_TFLOPs": 2.0 * out.shape[0] * hidden * H * D / t_op / 1e12 if world == 1 else None}
+        del y, w, proj
+
     # ---- dominant kernel alone, timed with events on the launch stream ----
     def timed(fn, iters, median=False):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
@@ -390,7 +489,6 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": t_attn_ms, "combine_ms": t_comb_ms, "index_build_ms": t_index_ms}
 
-    extra = {}
     if not args.no_baselines and rank == 0 and not fp8:
         # dense-causal baselines at the same shape (attention-op level)
         try:
@@ -506,18 +604,6 @@ def main():
             torch.cuda.synchronize(dev)
             cold.append(ea.elapsed_time(eb))
         extra["step_after_200ms_idle_ms"] = float(np.median(cold))
-
-    if args.oproj:
-        hidden = cfg["hidden"]
-        w = (torch.randn((hidden, H * D), device=dev) * 0.02).bfloat16()
-        proj = RowParallelOutputProjection(w, chunk_tokens=8192 if world > 1 else 0)
-        proj(out)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            proj(out)
-        sync_all()
-        extra["oproj_gemm_allreduce_ms"] = (time.perf_counter() - t0) / 5 * 1e3
 
     cpu = None
     if not args.no_baselines and rank == 0 and world == 1:

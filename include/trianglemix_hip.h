@@ -312,7 +312,8 @@ int tmx_attention(const tmx_attention_args_t* args, void* stream);
  * the split q-blocks is a fixed array of TMX_STATIC_WORKSPACE_BYTES inside the library's device image
  * (one copy per GPU, held until the process ends).  Steps whose partials need more
  * (num_partials * num_heads * block_m * (head_dim + 2) * 4 bytes, the first part rounded up to 256)
- * fail with TMX_ERR_CAPACITY and launch nothing.  The call allocates nothing and frees nothing.
+ * fail with TMX_ERR_CAPACITY and launch nothing.  The call allocates nothing and frees nothing (see
+ * tmx_static_workspace_warmup for its first call on a GPU).
  * All calls on one GPU share the array: two calls that overlap in time on one GPU (different streams)
  * race on it; calls on one stream are ordered and safe.  Nothing in it needs clearing between calls
  * (every partial row is written by its piece before the merge pass reads it).
@@ -320,6 +321,11 @@ int tmx_attention(const tmx_attention_args_t* args, void* stream);
 #define TMX_STATIC_WORKSPACE_BYTES (32u << 20)
 size_t tmx_static_workspace_bytes(void);
 int tmx_attention_static_ws(const tmx_attention_args_t* args, void* stream);
+/* The first tmx_attention_static_ws call on a GPU asks the runtime for the device address of the array
+ * (hipGetSymbolAddress, which may load the library's code object on that GPU: not something to do while a
+ * stream is being captured).  Callers that capture call this once per GPU beforehand, with that GPU current;
+ * afterwards tmx_attention_static_ws only launches kernels.  Idempotent, no counterpart in the reference. */
+int tmx_static_workspace_warmup(void);
 
 /* ------------------------------------------------------------------------
  * The eager attention of the reference in fp32 (ascend_trianglemix.py:88-106 run with fp32 tensors, the

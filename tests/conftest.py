@@ -32,6 +32,21 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """The largest error every attention parity check measured, per kernel / route (tests/parity_tolerance.py)."""
+    import parity_tolerance as tolerance  # tests/ is on sys.path (pytest's rootdir-relative imports)
+    if not tolerance.MEASURED:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_errors.json"), "w") as f:
+        json.dump(dict(bar="1e-3 * max(1, |ref|) (+ 2^-8 |ref| for 16-bit outputs)", measured=tolerance.MEASURED), f,
+                  indent=1, sort_keys=True)
+    print("\nattention parity, largest error per kernel / route (fraction of the bar, absolute):")
+    for what, m in sorted(tolerance.MEASURED.items()):
+        print(f"  {what:58s} {m['max_frac_of_bar']:.3f}  {m['max_abs']:.2e}  ({m['checks']} checks)")
+
+
 @pytest.fixture(scope="session")
 def golden_masks():
     with open(os.path.join(GOLDEN, "masks.json")) as f:

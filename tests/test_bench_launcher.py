@@ -23,6 +23,9 @@ def test_gpus_n_launches_n_ranks_by_itself():
     c = j["config"]
     assert (c["global_batch"], c["heads_per_gpu"], c["kv_heads_per_gpu"], c["seq_len"]) == (2, 16, 4, 32768)
     assert c["parallelism"] == "tp2 (heads)" and "Qwen3-8B" in j["metric"] and "32k" in j["metric"]
+    # the layer's exchange step (row-parallel o_proj, chunked all-reduce) ran over gloo and equalled the ranks' sum
+    x = j["extra"]
+    assert x["oproj_gemm_allreduce_ms"] > 0 and "layer_ms_with_oproj" in x and x["oproj"]["chunk_tokens"] == 64
 
 
 def test_model_configurations_of_the_tp_rows():
@@ -44,6 +47,38 @@ def test_too_few_devices_or_ranks_is_an_error_not_a_single_gpu_number():
     # a launcher that started fewer ranks than --gpus says: refuse instead of reporting n_gpus 1
     r = _bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "--gpus 4" in r.stderr
-    # a rank that dies takes the job down with a non-zero exit code
+    # a rank that dies takes the job down with a non-zero exit code, and the launcher shows that rank's stderr
     r = _bench("--gpus", "2", "--dry-run", "--model", "8b", "--seq-len", "-5")
-    assert r.returncode != 0
+    assert r.returncode != 0 and "Its stderr ends" in r.stderr and "Traceback" in r.stderr
+
+
+def test_the_launcher_counts_gpus_without_touching_one():
+    """The parent process must stay GPU-free (it goes on to start one process per GPU): the device count comes
+    from the visibility variables or from the kernel driver's topology files, never from a HIP call."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    keep = {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
+    try:
+        for k in keep:
+            os.environ.pop(k, None)
+        os.environ["HIP_VISIBLE_DEVICES"] = "0,1,2"
+        assert bench.visible_gpu_count() == 3
+        os.environ["CUDA_VISIBLE_DEVICES"] = "1"
+        assert bench.visible_gpu_count() == 1
+        os.environ["HIP_VISIBLE_DEVICES"] = ""
+        assert bench.visible_gpu_count() == 0
+        for k in keep:
+            os.environ.pop(k, None)
+        n = bench.visible_gpu_count()  # topology files (or None where the driver is absent)
+        assert n is None or n >= 0
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def launch_ranks"):src.index("def dry_run")]
+    assert "torch.cuda" not in body and "device_count" not in body

@@ -37,6 +37,8 @@ def _run(case, static_workspace, out=None):
 
 def test_static_workspace_entry_point_matches_the_allocating_one():
     assert _lib.load().tmx_static_workspace_bytes() == 32 << 20
+    # the set-up call a capturing caller makes once per GPU (resolves the array's device address); idempotent
+    assert _lib.load().tmx_static_workspace_warmup() == 0 and _lib.load().tmx_static_workspace_warmup() == 0
     H, Hkv, D = 8, 2, 128
     # first call: two long prompts + a decode row over a long context, many pieces (chunk 4);
     # second call, straight after on the same stream: a smaller step (fewer, other pieces)
@@ -63,7 +65,8 @@ def test_static_workspace_entry_point_matches_the_allocating_one():
     ref = orc.varlen_gqa_attention(q.float().cpu().numpy(), lambda b: kf[cuk_h[b]:cuk_h[b + 1]],
                                    lambda b: vf[cuk_h[b]:cuk_h[b + 1]], cu_h, [700, 900], D ** -0.5, "triangle",
                                    4, 32, 64)
-    assert float(np.abs(got_small.cpu().numpy() - ref).max()) <= 1e-3
+    from parity_tolerance import assert_close
+    assert_close(got_small.cpu().numpy(), ref, "tmx_attention_static_ws")
 
 
 def test_static_workspace_rejects_steps_beyond_its_size():

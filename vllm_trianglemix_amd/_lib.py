@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "tmx_abi_version", "tmx_last_error", "tmx_attention_block_m", "tmx_attention_block_n", "tmx_dense_mask",
     "tmx_replace_neg_inf", "tmx_index_sizes", "tmx_build_block_index", "tmx_attention", "tmx_reshape_and_cache",
     "tmx_reshape_and_cache_fp8", "tmx_gather_dequant_kv_fp8", "tmx_suggest_chunk_tiles",
-    "tmx_attention_static_ws", "tmx_static_workspace_bytes", "tmx_eager_attention_f32",
+    "tmx_attention_static_ws", "tmx_static_workspace_bytes", "tmx_static_workspace_warmup", "tmx_eager_attention_f32",
 )
 
 
@@ -109,6 +109,7 @@ def load() -> ctypes.CDLL:
                                             c_int64, c_int64, c_void_p]
     lib.tmx_static_workspace_bytes.argtypes = []
     lib.tmx_static_workspace_bytes.restype = ctypes.c_size_t
+    lib.tmx_static_workspace_warmup.argtypes = []
     lib.tmx_reshape_and_cache.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                           c_int64, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p]

@@ -1973,13 +1973,16 @@ __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p
 constexpr int kMaxDevices = 64;
 
 template <typename K>
-static int resident_workgroups(K kernel, unsigned* cache, long long* out, int* cus_out) {
+static int resident_workgroups(K kernel, std::atomic<unsigned>* cache, long long* out, int* cus_out) {
   int dev = 0;
   TMX_CHECK_HIP(hipGetDevice(&dev));
-  if (dev >= 0 && dev < kMaxDevices && cache[dev] != 0) {
-    *out = cache[dev] & 0xFFFFF;
-    *cus_out = (int)(cache[dev] >> 20);
-    return TMX_OK;
+  if (dev >= 0 && dev < kMaxDevices) {
+    const unsigned c = cache[dev].load(std::memory_order_relaxed);
+    if (c != 0) {
+      *out = c & 0xFFFFF;
+      *cus_out = (int)(c >> 20);
+      return TMX_OK;
+    }
   }
   int cus = 0, per_cu = 0;
   TMX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1987,8 +1990,10 @@ static int resident_workgroups(K kernel, unsigned* cache, long long* out, int* c
   if (per_cu < 1) per_cu = 1;
   *out = (long long)cus * per_cu;
   *cus_out = cus;
-  // (resident workgroups, CUs) packed into one word: same value from every thread
-  if (dev >= 0 && dev < kMaxDevices && cus < 4096 && *out < (1 << 20)) cache[dev] = ((unsigned)cus << 20) | (unsigned)*out;
+  // (resident workgroups, CUs) packed into one word: same value from every thread (host threads of different
+  // GPUs / streams may race here; the slot is atomic and every writer stores the same word)
+  if (dev >= 0 && dev < kMaxDevices && cus < 4096 && *out < (1 << 20))
+    cache[dev].store(((unsigned)cus << 20) | (unsigned)*out, std::memory_order_relaxed);
   return TMX_OK;
 }
 
@@ -2009,7 +2014,7 @@ constexpr int kRingSlotsFp8 = 4;  // fp8 K/V: entries of half the size, one more
 template <typename TR, int D, bool PAGED, bool HAS_BIAS, bool FP8 = false>
 static int launch_attn(const AttnParams& p_in, hipStream_t s) {
   auto kernel = attn_kernel<TR, D, FP8 ? kRingSlotsFp8 : kRingSlots, PAGED, HAS_BIAS, FP8>;
-  static unsigned resident_cache[kMaxDevices] = {0};  // per device: resident workgroups of this instantiation
+  static std::atomic<unsigned> resident_cache[kMaxDevices];  // per device: resident workgroups of this instantiation (0: not asked yet)
   long long resident = 0;
   int cus = 0;
   int rc = resident_workgroups(kernel, resident_cache, &resident, &cus);
@@ -2187,6 +2192,9 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   TMX_CHECK_SUPPORTED(a->num_items < (1ll << 30), "tmx_attention: more than 2^30 work items");
   TMX_CHECK_ARG(a->num_items <= ix->cap_items && a->num_split_qblocks <= ix->cap_split,
                 "tmx_attention: num_items / num_split_qblocks exceed the index capacities");
+  // (every partial slot belongs to a piece, and every piece is an item)
+  TMX_CHECK_ARG(a->num_partials <= a->num_items, "tmx_attention: num_partials %lld exceeds num_items %lld",
+                (long long)a->num_partials, (long long)a->num_items);
   TMX_CHECK_ARG(a->q && a->out && a->k && a->v && a->cu_seqlens_q && a->seq_lens, "tmx_attention: NULL tensor");
   TMX_CHECK_ARG(ix->items && ix->qb_meta && ix->col_idx && ix->part_ptr, "tmx_attention: NULL index buffer");
   TMX_CHECK_ARG(a->num_partials == 0 || (a->partial_o && a->partial_ml && a->num_split_qblocks > 0 && ix->split_qb),
@@ -2493,6 +2501,11 @@ static int static_ws_base(unsigned char** out) {
 
 extern "C" size_t tmx_static_workspace_bytes(void) { return tmx::kStaticWsBytes; }
 
+extern "C" int tmx_static_workspace_warmup(void) {
+  unsigned char* base = nullptr;
+  return tmx::static_ws_base(&base);
+}
+
 extern "C" int tmx_attention_static_ws(const tmx_attention_args_t* a, void* stream) {
   using namespace tmx;
   TMX_CHECK_ARG(a != nullptr, "tmx_attention_static_ws: args is NULL");
@@ -2505,12 +2518,17 @@ extern "C" int tmx_attention_static_ws(const tmx_attention_args_t* a, void* stre
   if (a->num_partials > 0) {
     TMX_CHECK_ARG(a->index != nullptr && a->num_heads > 0 && a->head_dim > 0 && a->index->block_m > 0,
                   "tmx_attention_static_ws: bad sizes");
+    // bounds ahead of the products below, so that none of them can wrap (a slot is a piece, a piece an item)
+    TMX_CHECK_ARG(a->num_partials <= a->num_items && a->num_items < (1ll << 30) && a->num_heads < (1 << 16) &&
+                      a->head_dim <= 1024 && a->index->block_m <= 1024,
+                  "tmx_attention_static_ws: num_partials %lld / num_heads %d / head_dim %d out of range",
+                  (long long)a->num_partials, a->num_heads, a->head_dim);
     // partial_o [P][H][block_m][D] floats, then partial_ml [P][H][block_m][2] floats on the next 256-byte boundary
     const unsigned long long rows = (unsigned long long)a->num_partials * (unsigned long long)a->num_heads *
                                     (unsigned long long)a->index->block_m;
     const unsigned long long o_bytes = (rows * (unsigned long long)a->head_dim * 4ull + 255ull) & ~255ull;
     const unsigned long long need = o_bytes + rows * 8ull;
-    if (rows > (1ull << 40) || need > kStaticWsBytes) {
+    if (need > kStaticWsBytes) {
       set_error("tmx_attention_static_ws: the split q-blocks of this step need %llu bytes of work area, the library "
                 "holds %zu (use tmx_attention with a workspace of your own, or longer pieces)", need, kStaticWsBytes);
       return TMX_ERR_CAPACITY;

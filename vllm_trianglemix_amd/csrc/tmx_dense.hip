@@ -22,6 +22,8 @@
 //
 // Requests with fewer than kDenseMinRows query rows (decode, speculative decode) stay on the work-list kernel.
 #include "tmx_common.h"
+
+#include <atomic>
 #include "tmx_dense.h"
 
 #include <type_traits>
@@ -497,13 +499,13 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
 namespace tmx {
 
 int launch_dense_causal(const DenseParams& p, bool bf16, bool paged, hipStream_t s) {
-  static unsigned cus_cache[64] = {0};
+  static std::atomic<unsigned> cus_cache[64];  // CUs per device, asked once (host threads of different GPUs may meet here)
   int dev = 0;
   TMX_CHECK_HIP(hipGetDevice(&dev));
-  int cus = (dev >= 0 && dev < 64) ? (int)cus_cache[dev] : 0;
+  int cus = (dev >= 0 && dev < 64) ? (int)cus_cache[dev].load(std::memory_order_relaxed) : 0;
   if (cus == 0) {
     TMX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (dev >= 0 && dev < 64) cus_cache[dev] = (unsigned)cus;
+    if (dev >= 0 && dev < 64) cus_cache[dev].store((unsigned)cus, std::memory_order_relaxed);
   }
   if (paged) {
     // (the cache-only fetch adds a 32-bit lane offset, row inside the page x row pitch, to a wave-uniform base)

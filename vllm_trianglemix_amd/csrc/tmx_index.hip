@@ -443,7 +443,9 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IndexParams p) {
   if (p.blocked) {
     // prefixes inside the q-block's block + the totals of the blocks before it; the grand totals
     const int num_qblocks = p.blk_tot[5];
-    const int nblk = (num_qblocks + 1023) >> 10, myblk = qb >> 10;
+    // only the blocks that were launched (and have a place in the work area) wrote their totals: the device's
+    // count may exceed the capacity the caller sized for, which is exactly the case the check below refuses
+    const int nblk = imin((num_qblocks + 1023) >> 10, (p.cap_qblocks + 1023) >> 10), myblk = qb >> 10;
     Int4 off{0, 0, 0, 0}, all{0, 0, 0, 0};
     int maxt = 0;
     for (int k = lane; k < nblk; k += 64) {

@@ -196,6 +196,14 @@ class BlockIndex:
     def tile_pages(self) -> Optional[torch.Tensor]:                # [nnz, 2] or None
         return self._arr("tile_pages").view(-1, 2) if "tile_pages" in self._off else None
 
+    def pages_resolved_from(self, block_table: Optional[torch.Tensor], page_size: int) -> bool:
+        """True when ``tile_pages`` holds the physical pages of exactly this block table (same memory, same row
+        stride) at this page size: only then may an attention call read them instead of the block table."""
+        bt = self.block_table
+        return (bt is not None and block_table is not None and "tile_pages" in self._off
+                and bt.data_ptr() == block_table.data_ptr() and bt.stride(0) == block_table.stride(0)
+                and int(self.c.pages_page_size) == int(page_size))
+
     @property
     def num_qblocks(self) -> int:
         return int(self.sizes.num_qblocks)
@@ -338,9 +346,14 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
             part_o, part_ml = workspace
         elif n_part > 0:
             part_o, part_ml = alloc_workspace(index, q.shape[1], q.shape[2], q.device)
+        # the operator stamps the call's own block table on the index it hands to the library, so the pages the
+        # builder resolved go along only when they were resolved from that very table and page size (an index
+        # used with another table falls back to the kernel's own block-table lookups, as the ctypes route does)
+        if tile_pages is not None and not index.pages_resolved_from(block_table, k.shape[1] if k.dim() == 4 else 0):
+            tile_pages = None
         try:
             C.trianglemix_attention(out, q, k, v, block_table, cu_seqlens_q, seq_lens, cu_seqlens_k, index_list,
-                                    tile_pages if block_table is not None else None, part_o, part_ml, bias, float(scale),
+                                    tile_pages, part_o, part_ml, bias, float(scale),
                                     index.si, index.sl, index.last, index.mode, index.tri_min_len, index.chunk_tiles,
                                     n_items, n_part, n_split, index.full_lens, int(flags), nnz, k_new, v_new, cache_slots,
                                     float(k_scale), float(v_scale), index.block_m, index.block_n)

@@ -67,11 +67,14 @@ class RowParallelOutputProjection(torch.nn.Module):
     (the all-reduce of a 32k-token prompt is hundreds of MiB)."""
 
     def __init__(self, weight_shard: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
-                 chunk_tokens: int = 0):
+                 chunk_tokens: int = 0, always_reduce: bool = False):
         super().__init__()
         self.weight_shard = weight_shard  # [hidden, local_heads * head_dim]
         self.group = group
         self.chunk_tokens = chunk_tokens
+        # a group of ONE rank normally skips the collective (nothing to sum); with always_reduce the chunked
+        # GEMM + all-reduce pipeline runs all the same, so that it can be exercised on a single GPU
+        self.always_reduce = always_reduce
         self._comm_stream = None
 
     def forward(self, attn_out: torch.Tensor) -> torch.Tensor:
@@ -79,7 +82,7 @@ class RowParallelOutputProjection(torch.nn.Module):
         t = attn_out.shape[0]
         x = attn_out.reshape(t, -1)
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world == 1:
+        if world == 1 and not (self.always_reduce and dist.is_initialized()):
             return x @ self.weight_shard.t()
         if self.chunk_tokens <= 0 or t <= self.chunk_tokens:
             y = x @ self.weight_shard.t()
