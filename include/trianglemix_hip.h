@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TMX_ABI_VERSION 4
+#define TMX_ABI_VERSION 5
 /* int32 entries of tmx_index_t.scratch for a batch of `batch` requests and a capacity of R q-blocks */
 #define TMX_INDEX_SCRATCH_INTS(batch, R) ((batch) + 1 + 2 * ((R) + 1) + 8 * ((R) / 1024 + 1))
 
@@ -326,6 +326,61 @@ int tmx_attention_static_ws(const tmx_attention_args_t* args, void* stream);
  * stream is being captured).  Callers that capture call this once per GPU beforehand, with that GPU current;
  * afterwards tmx_attention_static_ws only launches kernels.  Idempotent, no counterpart in the reference. */
 int tmx_static_workspace_warmup(void);
+
+/* ------------------------------------------------------------------------
+ * A step of one-row requests (decode) with a launch whose shape does not depend on the requests' lengths:
+ * what a caller needs to capture the step in a HIP graph and replay it with other lengths and block tables,
+ * as the reference's ROCm backend allows (cudagraph_support = AttentionCGSupport.ALWAYS,
+ * vllm/v1/attention/backends/rocm_attn.py:63; its decode call: rocm_attn.py:398-426).  No index, no host
+ * copies of the batch: request b owns query row b, which sits at position seq_lens[b] - 1 and attends to
+ * every key of its sequence -- what the reference's pattern gives for every decode row (the last row always
+ * lies among the trailing dense rows, trianglemix_attention.py:126-129, provided last >= 2) and what a layer
+ * outside the triangle set computes.  Paged K/V, head_dim 128, query-head groups that are multiples of 4;
+ * 16-bit or fp8 (e4m3fn) caches; k_new / v_new / cache_slots as in tmx_attention_args_t (row b = request b's
+ * newest key / value; the call then also stores it to its slot).
+ *
+ * The launch depends on the batch size alone.  Its pieces are laid out on the device, by every workgroup for
+ * itself, from seq_lens: with T the 32-key tiles of all requests, pieces are P = max(8, ceil(T * units / slots))
+ * tiles long (slots = two workgroups per CU; units = K/V head chunks per piece), so that a step fills the chip
+ * whatever its lengths are; the grid provides for slots / units + batch pieces, which no step of that batch size
+ * exceeds, and workgroups beyond the step's pieces return at once.  seq_lens[b] <= 0 marks a padding row: nothing
+ * is read and out row b is left alone.  Requests that take more than one piece go through partial results in the
+ * caller's work area and a merge launch: partial_o [rows][head_dim] floats, partial_ml [rows][2] floats, rows =
+ * tmx_decode_workspace_rows(batch, ...) (num_cus <= 0 asks the current device; -1 on a HIP error).  A captured
+ * launch replays with the pointers it was captured with: keep the work area.  Nothing is allocated, nothing
+ * synchronises with the host.
+ * ---------------------------------------------------------------------- */
+typedef struct tmx_decode_args_t {
+  uint32_t struct_size; /* sizeof(tmx_decode_args_t), ABI check */
+  int32_t io_dtype;     /* q element type: TMX_BF16 or TMX_F16 */
+  int32_t out_dtype;    /* == io_dtype, or TMX_F32 */
+  float scale;
+  int32_t batch, num_heads, num_kv_heads, head_dim;
+  void* out;            /* (device) [batch, num_heads, head_dim] */
+  int64_t out_stride_t, out_stride_h;
+  const void* q;        /* (device) [batch, num_heads, head_dim] */
+  int64_t q_stride_t, q_stride_h;
+  const void* k;        /* paged cache [num_blocks, page_size, num_kv_heads, head_dim] */
+  const void* v;
+  int64_t kv_stride_page, kv_stride_t, kv_stride_h; /* elements (fp8: bytes) */
+  const int32_t* block_table; /* (device) [batch, block_table_stride] */
+  int64_t block_table_stride;
+  int32_t page_size;
+  int32_t kv_dtype;     /* 0 / io_dtype, or TMX_FP8_E4M3 */
+  float k_scale, v_scale;
+  const void* k_new;    /* optional (16-bit cache): [batch, num_kv_heads, head_dim], row b = request b's newest key */
+  const void* v_new;
+  int64_t new_stride_t, new_stride_h;
+  const int64_t* cache_slots; /* optional, with k_new / v_new: (device) [batch], negative = skipped */
+  const int32_t* seq_lens;    /* (device) [batch] */
+  float* partial_o;     /* work area (see above) */
+  float* partial_ml;
+  int64_t workspace_rows; /* rows the work area holds */
+  uint32_t flags, reserved; /* 0 */
+} tmx_decode_args_t;
+
+int64_t tmx_decode_workspace_rows(int batch, int num_heads, int num_kv_heads, int kv_dtype, int num_cus);
+int tmx_decode_attention(const tmx_decode_args_t* args, void* stream);
 
 /* ------------------------------------------------------------------------
  * The eager attention of the reference in fp32 (ascend_trianglemix.py:88-106 run with fp32 tensors, the

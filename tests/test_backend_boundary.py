@@ -26,7 +26,11 @@ def test_cudagraph_support_is_consumed_like_the_model_runner_does():
         if b.cudagraph_support.value < min_cg_support.value:
             min_cg_support = b.cudagraph_support
             min_cg_builder_name = b.__class__.__name__
-    assert min_cg_support is AttentionCGSupport.NEVER and min_cg_support != AttentionCGSupport.ALWAYS
+    # decode steps replay under a graph; steps with prompts do not (FULL mixed mode resolves to
+    # FULL_DECODE_ONLY / FULL_AND_PIECEWISE at gpu_model_runner.py:3620-3643, and the check at :3645-3647 that
+    # refuses decode graphs for NEVER does not fire)
+    assert min_cg_support is AttentionCGSupport.UNIFORM_SINGLE_TOKEN_DECODE
+    assert min_cg_support != AttentionCGSupport.ALWAYS and min_cg_support != AttentionCGSupport.NEVER
     assert min_cg_builder_name == "TriangleMixMetadataBuilder"
     assert isinstance(TriangleMixMetadataBuilder.cudagraph_support, enum.Enum)
     # the base class's members (vllm/v1/attention/backends/utils.py:232-341)
@@ -46,8 +50,30 @@ def test_builder_entry_points_of_the_base_class():
         seq_lens=torch.tensor([3], dtype=torch.int32), seq_lens_cpu=torch.tensor([3], dtype=torch.int32),
         block_table_tensor=torch.zeros((1, 1), dtype=torch.int32), slot_mapping=torch.arange(3, dtype=torch.int64))
     for md in (builder.build(common_prefix_len=0, common_attn_metadata=common, fast_build=True),
-               builder.build_for_cudagraph_capture(common), builder.build_for_drafting(common, draft_index=0)):
+               builder.build_for_drafting(common, draft_index=0)):
         assert isinstance(md, TriangleMixAttentionBackend.get_metadata_cls()) and md.num_actual_tokens == 3
+        assert not md.uniform_decode and not md.capturing
+    # a graph is captured from uniform single-token decode steps only; a step with a prompt is refused
+    with pytest.raises(NotImplementedError):
+        builder.build_for_cudagraph_capture(common)
+    # the capture batch the runner builds (gpu_model_runner.py:3612-3619 has read cudagraph_support): one token per
+    # request; the layers' launches then depend on the batch size alone, whatever lengths the capture batch carries
+    decode = types.SimpleNamespace(
+        num_actual_tokens=4, max_query_len=1, max_seq_len=9,
+        query_start_loc=torch.arange(5, dtype=torch.int32), query_start_loc_cpu=torch.arange(5, dtype=torch.int32),
+        seq_lens=torch.tensor([9, 1, 1, 1], dtype=torch.int32), seq_lens_cpu=torch.tensor([9, 1, 1, 1], dtype=torch.int32),
+        block_table_tensor=torch.zeros((4, 1), dtype=torch.int32), slot_mapping=torch.arange(4, dtype=torch.int64))
+    md = builder.build_for_cudagraph_capture(decode)
+    assert md.capturing and md.uniform_decode and md.builder is builder
+    md = builder.build(0, decode)  # the same step outside a capture
+    assert not md.capturing and md.uniform_decode
+    # which layers can take the fixed-shape decode launch
+    mk = lambda **kw: TriangleMixAttentionImpl(kw.pop("H", 32), kw.pop("D", 128), 0.1, kw.pop("Hkv", 8), None, None, "auto",  # noqa: E731
+                                               None, "decoder", None, **kw)
+    assert mk(use_triangle=True)._decode_fixed_ok() and mk(use_triangle=False)._decode_fixed_ok()
+    assert not mk(use_triangle=True, num_last_tokens=1)._decode_fixed_ok()   # the decode row would be sparse
+    assert mk(use_triangle=False, num_last_tokens=1)._decode_fixed_ok()
+    assert not mk(D=64)._decode_fixed_ok() and not mk(H=6, Hkv=2)._decode_fixed_ok()
 
 
 def test_backend_name_is_tolerated_by_the_selector_lookup():

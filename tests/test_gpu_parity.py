@@ -725,6 +725,45 @@ def test_head_shards_through_the_output_projection(H, Hkv, world):
     assert (total - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
 
 
+def test_chunked_output_projection_on_the_gpu():
+    """RowParallelOutputProjection with chunk_tokens > 0 on device tensors: chunks of the token dimension go through
+    GEMM + all-reduce in turn, the all-reduce of one chunk on a second HIP stream beside the GEMM of the next
+    (linear.py:1358-1359 is the reference's single all-reduce).  On one GPU the group has one rank (RCCL, world size
+    1; ``always_reduce`` keeps the pipeline running although there is nothing to sum): the result must equal the
+    unchunked product, and what follows on the caller's stream must see all of it."""
+    import socket
+    import torch.distributed as dist
+    from vllm_trianglemix_amd.parallel import RowParallelOutputProjection
+    T, H, D, hidden = 5000, 8, 128, 1024  # chunks of 1024 tokens: four whole ones and a ragged last one
+    g = torch.Generator(device="cpu").manual_seed(12)
+    x = torch.randn((T, H, D), generator=g).to(DEV).bfloat16()
+    w = (torch.randn((hidden, H * D), generator=g) * 0.03).to(DEV).bfloat16()
+    whole = RowParallelOutputProjection(w)(x)  # no group: the plain product
+    started = False
+    if not dist.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device(DEV))
+        started = True
+    try:
+        proj = RowParallelOutputProjection(w, chunk_tokens=1024, always_reduce=True)
+        got = proj(x)
+        after = got.float().sum()  # queued on the caller's stream straight behind the call
+        one = RowParallelOutputProjection(w, chunk_tokens=0, always_reduce=True)(x)  # one GEMM, one all-reduce
+        torch.cuda.synchronize()
+        assert proj._comm_stream is not None
+        for name, y in (("chunked", got), ("single all-reduce", one)):
+            err = (y.float() - whole.float()).abs().max().item()
+            # (a GEMM over fewer rows may sum in another order: bf16 outputs one ulp apart)
+            assert err <= 2.0 ** -7 * max(1.0, whole.float().abs().max().item()), (name, err)
+        assert abs(after.item() - got.float().sum().item()) <= 1e-3 * abs(got.float().sum().item()) + 1e-3
+    finally:
+        if started:
+            dist.destroy_process_group()
+
+
 def test_reshape_and_cache_and_errors():
     ops = _ops()
     from vllm_trianglemix_amd._lib import TmxError
@@ -918,12 +957,16 @@ def test_backend_whole_prompt_step_reads_rows_beside_cache_write(monkeypatch):
     assert_close(out2.float().cpu().numpy().reshape(B, H, D), ref2, "backend forward, decode step", out16=True)
 
 
-def test_backend_pure_decode_step():
-    """A step of decode rows only (the backend then cuts the contexts into pieces that fill the chip): every row is
-    the dense last row of the pattern, contexts from one page to several pieces."""
+@pytest.mark.parametrize("route", ["fixed launch shape", "block index"])
+def test_backend_pure_decode_step(monkeypatch, route):
+    """A step of decode rows only: every row is the dense last row of the pattern, contexts from one page to several
+    pieces.  By default the layers take the launch with a fixed shape (no index is built); with
+    TRIANGLEMIX_DECODE_FIXED=0 the step goes through the block index, cut into pieces that fill the chip."""
     import types
     from vllm_trianglemix_amd import TriangleMixConfig
+    from vllm_trianglemix_amd import backend as be
     from vllm_trianglemix_amd.backend import TriangleMixAttentionBackend
+    monkeypatch.setattr(be, "_DECODE_FIXED", route == "fixed launch shape")
     H, Hkv, D, page = 8, 2, 128, 16
     seq_lens = [9000, 4100, 1, 17, 2049, 600]
     q_lens = [1] * len(seq_lens)
@@ -965,14 +1008,21 @@ def test_backend_pure_decode_step():
     impl.forward(None, _to_dev(q, torch.bfloat16), _to_dev(k_new, torch.bfloat16), _to_dev(v_new, torch.bfloat16),
                  kv_cache, md, output=out)
     torch.cuda.synchronize()
-    (idx,) = md._indices.values()
-    # 497 tiles x 2 head groups for 512 workgroup slots: the shortest pieces the advice gives (8 tiles)
-    tiles = [-(-s // 32) for s in seq_lens]
-    assert idx.chunk_tiles == 8
-    assert idx.sizes.num_partials == sum(-(-t // 8) for t in tiles if t > 8)
+    if route == "block index":
+        (idx,) = md._indices.values()
+        # 497 tiles x 2 head groups for 512 workgroup slots: the shortest pieces the advice gives (8 tiles)
+        tiles = [-(-s // 32) for s in seq_lens]
+        assert idx.chunk_tiles == 8
+        assert idx.sizes.num_partials == sum(-(-t // 8) for t in tiles if t > 8)
+    else:
+        assert not md._indices and md.uniform_decode
     got = out.float().cpu().numpy().reshape(B, H, D)
     ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu, seq_lens, scale, "causal", 0, 0, 0)
-    assert_close(got, ref, "backend forward, decode step", out16=True)
+    assert_close(got, ref, f"backend forward, decode step ({route})", out16=True)
+    # the step's rows are in the cache afterwards
+    flat = kv_cache.view(2, -1, Hkv, D)
+    sd = torch.from_numpy(slots).to(DEV)
+    assert torch.equal(flat[0][sd], _to_dev(k_new, torch.bfloat16)) and torch.equal(flat[1][sd], _to_dev(v_new, torch.bfloat16))
 
 
 def test_fp8_kv_cache_write_gather_and_backend():
@@ -1368,6 +1418,215 @@ def test_decode_kernel_matches_oracle_and_work_list(case):
     for name, flags in variants:
         got = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, mode, pat, flags=flags, **kw)
         assert_close(got, ref, f"decode rows: {name}, {str(dtype)[6:]}", out16=out_dtype != torch.float32)
+
+
+def _paged_decode_batch(seq_lens, Hkv, D, page, dtype, seed, ks, vs, fp8_scales=None, extra_pages=0, pad_rows=0):
+    """A paged cache holding every request's keys (shuffled pages), its block table, and the flat slot of each
+    request's LAST key.  ``pad_rows``: block-table rows beyond the requests (padding of a captured batch)."""
+    ops = _ops()
+    B = len(seq_lens)
+    nblk = sum((s + page - 1) // page for s in seq_lens) + 2 + extra_pages
+    perm = np.random.default_rng(seed).permutation(nblk).astype(np.int32)
+    cache_dtype = torch.uint8 if fp8_scales else dtype
+    kc = torch.zeros((nblk, page, Hkv, D), dtype=cache_dtype, device=DEV)
+    vc = torch.zeros_like(kc)
+    width = max([(s + page - 1) // page for s in seq_lens] + [1]) + extra_pages
+    bt = np.zeros((B + pad_rows, width), np.int32)
+    last_slot = np.full((B + pad_rows,), -1, np.int64)
+    nxt = 0
+    for b, s in enumerate(seq_lens):
+        for pb in range((s + page - 1) // page):
+            bt[b, pb] = perm[nxt]
+            nxt += 1
+        if s == 0:
+            continue
+        pos = np.arange(s)
+        slots = bt[b, pos // page].astype(np.int64) * page + pos % page
+        last_slot[b] = slots[-1]
+        sd = torch.from_numpy(slots).to(DEV)
+        if fp8_scales:
+            ops.reshape_and_cache_fp8(_to_dev(ks[b], dtype), _to_dev(vs[b], dtype), kc, vc, sd, *fp8_scales)
+        else:
+            ops.reshape_and_cache(_to_dev(ks[b], dtype), _to_dev(vs[b], dtype), kc, vc, sd)
+    return kc, vc, torch.from_numpy(bt).to(DEV), last_slot
+
+
+@pytest.mark.parametrize("case", [
+    dict(H=8, Hkv=2),                                            # 32 tiles in all: pieces of 8 tiles, the merge launch
+    dict(H=32, Hkv=8, page=64),                                  # Qwen3-8B heads
+    dict(H=16, Hkv=2, dtype=torch.float16),                      # 8 query heads per workgroup
+    dict(H=8, Hkv=1, out=torch.bfloat16, big=True),              # longer pieces (a larger step), bf16 output
+    dict(H=16, Hkv=2, fp8=(0.75, 1.5)),                          # fp8 cache, descaled in registers
+    dict(H=8, Hkv=1, fp8=(1.0, 1.0), dtype=torch.float16, out=torch.float16, big=True),
+    dict(H=8, Hkv=2, many=True),                                 # more requests than threads of a workgroup
+    dict(H=8, Hkv=2, binding="ctypes", fp8=(0.75, 1.5)),         # the ctypes binding of the same entry point
+])
+def test_decode_attention_with_a_fixed_launch_shape(monkeypatch, case):
+    """tmx_decode_attention: a step of one-row requests with no index -- every workgroup lays the step's pieces out
+    from seq_lens on the device and finds its own.  Lengths around the 16-key groups, the 32-key tiles and the pieces'
+    ends; padding rows (length 0) are left alone; same rows as the oracle (every key of the sequence attended: what
+    the pattern gives for a decode row)."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "_BINDING", case.get("binding", "torch"))
+    H, Hkv, D = case["H"], case["Hkv"], 128
+    page = case.get("page", 16)
+    dtype, out_dtype, fp8 = case.get("dtype", torch.bfloat16), case.get("out", torch.float32), case.get("fp8")
+    seq_lens = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 0, 127, 128, 129, 255, 256, 257, 700, 1023, 2049, 3000, 4100, 0]
+    if case.get("big"):
+        seq_lens += [9000, 12000, 300, 8192, 8193]   # ~1500 tiles: pieces of 12 or 24 tiles, uneven ends
+    if case.get("many"):
+        seq_lens = seq_lens + [int(x) for x in np.random.default_rng(2).integers(0, 90, size=300)]  # 324 requests
+    B = len(seq_lens)
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else (lambda x: np.float16(x).astype(np.float32))
+    q, ks, vs = _rand_case(6400 + H, [1] * B, [max(s, 1) for s in seq_lens], H, Hkv, D)
+    q, ks, vs = rnd(q), [rnd(k[:s]) for k, s in zip(ks, seq_lens)], [rnd(v[:s]) for v, s in zip(vs, seq_lens)]
+    ks[20][40] = rnd(3.0 * q[20, ::H // Hkv])  # one key far above the others early in a long row
+    kc, vc, bt, _ = _paged_decode_batch(seq_lens, Hkv, D, page, dtype, 5, ks, vs, fp8_scales=fp8)
+    if fp8:
+        seen = lambda x, sc: rnd(orc.fp8_cache_roundtrip(x, sc).astype(np.float32))  # noqa: E731
+        ks, vs = [seen(k, fp8[0]) for k in ks], [seen(v, fp8[1]) for v in vs]
+    ws = ops.decode_workspace(B, H, Hkv, D, DEV, bool(fp8))
+    sld = torch.tensor(seq_lens, dtype=torch.int32, device=DEV)
+    out = torch.full((B, H, D), 7.0, dtype=out_dtype, device=DEV)
+    scale = D ** -0.5
+    ops.decode_attention(_to_dev(q, dtype), kc, vc, out, bt, sld, scale, ws,
+                         k_scale=fp8[0] if fp8 else 1.0, v_scale=fp8[1] if fp8 else 1.0)
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    live = [b for b, s in enumerate(seq_lens) if s > 0]
+    pad = [b for b, s in enumerate(seq_lens) if s == 0]
+    assert np.all(got[pad] == 7.0)
+    ref = orc.varlen_gqa_attention(q[live], lambda i: ks[live[i]], lambda i: vs[live[i]], np.arange(len(live) + 1),
+                                   [seq_lens[b] for b in live], scale, "causal", 0, 0, 0)
+    what = f"decode rows, fixed launch shape{', fp8 cache' if fp8 else ''}, {str(dtype)[6:]}"
+    assert_close(got[live], ref, what, out16=out_dtype != torch.float32, info=case)
+    with pytest.raises(RuntimeError):  # the work area is the caller's to provide, at the size of the batch
+        small = ops.decode_workspace(1, H, Hkv, D, DEV, bool(fp8))
+        ops.decode_attention(_to_dev(q, dtype), kc, vc, out, bt, sld, scale, small)
+
+
+def test_decode_step_replays_under_a_graph():
+    """A decode step through the backend, captured in a graph (torch.cuda.graph) the way the model runner does it:
+    metadata from build_for_cudagraph_capture over persistent buffers, a warm-up call, the capture, then replays after
+    seq_lens, the block table, the slot mapping, the cache and the step's q / k / v were changed IN PLACE (other
+    lengths, other pages, fewer live requests: the rest are padding rows).  Every replay must give the oracle's
+    rows and leave the step's K/V rows in the cache, for a triangle layer, a causal layer and an fp8-cache layer.
+    (rocm_attn.py:63 declares ALWAYS for the reference's ROCm backend; this one replays decode steps.)"""
+    import types
+    from vllm_trianglemix_amd import TriangleMixConfig
+    from vllm_trianglemix_amd.backend import AttentionCGSupport, TriangleMixAttentionBackend
+    H, Hkv, D, page, cap, max_len = 8, 2, 128, 16, 6, 5000
+    scale = D ** -0.5
+    builder_cls = TriangleMixAttentionBackend.get_builder_cls()
+    assert builder_cls.cudagraph_support is AttentionCGSupport.UNIFORM_SINGLE_TOKEN_DECODE
+    vllm_config = types.SimpleNamespace(model_config=types.SimpleNamespace(max_model_len=max_len))
+    builder = builder_cls(types.SimpleNamespace(block_size=page), ["l0", "l1"], vllm_config, torch.device(DEV))
+    steps = [[4100, 1, 333, 2049, 64, 17], [900, 4999, 2, 1500], [31, 32, 33, 4097, 700, 5000]]
+    width = (max_len + page - 1) // page + 1
+    nblk_cap = cap * width + 4
+    # the runner's persistent buffers
+    seq_buf = torch.zeros((cap,), dtype=torch.int32, device=DEV)
+    bt_buf = torch.zeros((cap, width), dtype=torch.int32, device=DEV)
+    slot_buf = torch.full((cap,), -1, dtype=torch.int64, device=DEV)
+    qsl = torch.arange(cap + 1, dtype=torch.int32, device=DEV)
+    q_buf = torch.zeros((cap, H * D), dtype=torch.bfloat16, device=DEV)
+    k_buf = torch.zeros((cap, Hkv * D), dtype=torch.bfloat16, device=DEV)
+    v_buf = torch.zeros_like(k_buf)
+    caches = {"bf16": torch.zeros((2, nblk_cap, page, Hkv, D), dtype=torch.bfloat16, device=DEV),
+              "fp8": torch.zeros((2, nblk_cap, page, Hkv, D), dtype=torch.uint8, device=DEV)}
+    k_scale, v_scale = 0.75, 1.5
+    layer = types.SimpleNamespace(_k_scale_float=k_scale, _v_scale_float=v_scale)
+    impl_cls = TriangleMixAttentionBackend.get_impl_cls()
+    cfg = TriangleMixConfig(num_triangle_layers=1)
+    layers = [("triangle layer", impl_cls(H, D, scale, Hkv, None, None, "auto", None, "decoder", None, trianglemix_config=cfg, layer_idx=0), "bf16"),
+              ("causal layer", impl_cls(H, D, scale, Hkv, None, None, "auto", None, "decoder", None, trianglemix_config=cfg, layer_idx=1), "bf16"),
+              ("fp8-cache layer", impl_cls(H, D, scale, Hkv, None, None, "fp8", None, "decoder", None, trianglemix_config=cfg, layer_idx=0), "fp8")]
+    outs = [torch.zeros((cap, H * D), dtype=torch.bfloat16, device=DEV) for _ in layers]
+
+    def common(max_seq):
+        return types.SimpleNamespace(
+            num_actual_tokens=cap, max_query_len=1, max_seq_len=max_seq, query_start_loc=qsl,
+            query_start_loc_cpu=torch.arange(cap + 1, dtype=torch.int32), seq_lens=seq_buf,
+            seq_lens_cpu=torch.ones((cap,), dtype=torch.int32), block_table_tensor=bt_buf, slot_mapping=slot_buf)
+
+    def load_step(i, seq_lens):
+        """Write step i's batch into the persistent buffers; returns what the oracle needs."""
+        B = len(seq_lens)
+        q, ks, vs = _rand_case(7000 + 10 * i, [1] * B, seq_lens, H, Hkv, D)
+        q, ks, vs = orc.bf16_round(q), [orc.bf16_round(k) for k in ks], [orc.bf16_round(v) for v in vs]
+        for name, cache in caches.items():
+            # the context (all keys but the newest) is in the cache; the newest key / value is the step's row
+            ctx_k, ctx_v = [k[:-1] for k in ks], [v[:-1] for v in vs]
+            kc, vc, bt, _ = _paged_decode_batch([s - 1 for s in seq_lens], Hkv, D, page, torch.bfloat16, 40 + i, ctx_k, ctx_v,
+                                                fp8_scales=(k_scale, v_scale) if name == "fp8" else None,
+                                                extra_pages=1, pad_rows=cap - B)
+            cache.zero_()
+            cache[0, :kc.shape[0]], cache[1, :vc.shape[0]] = kc, vc
+        bt_buf.zero_()
+        bt_buf[:bt.shape[0], :bt.shape[1]] = bt
+        btn = bt_buf.cpu().numpy()
+        # (the page of every request's newest key: the layout above left one page to spare per request)
+        for b, s in enumerate(seq_lens):
+            if (s - 1) % page == 0:
+                used = set(btn[:B, :].ravel().tolist()) | {0}
+                btn[b, (s - 1) // page] = max(used) + 1 + b
+        bt_buf.copy_(torch.from_numpy(btn).to(DEV))
+        slots = np.full((cap,), -1, np.int64)
+        for b, s in enumerate(seq_lens):
+            slots[b] = int(btn[b, (s - 1) // page]) * page + (s - 1) % page
+        slot_buf.copy_(torch.from_numpy(slots).to(DEV))
+        seq_buf.zero_()
+        seq_buf[:B] = torch.tensor(seq_lens, dtype=torch.int32, device=DEV)
+        q_buf.zero_(); k_buf.zero_(); v_buf.zero_()
+        q_buf[:B] = _to_dev(q, torch.bfloat16).view(B, H * D)
+        k_buf[:B] = _to_dev(np.stack([k[-1] for k in ks]), torch.bfloat16).view(B, Hkv * D)
+        v_buf[:B] = _to_dev(np.stack([v[-1] for v in vs]), torch.bfloat16).view(B, Hkv * D)
+        return q, ks, vs, slots
+
+    def run_layers(md):
+        for (name, impl, cache), out in zip(layers, outs):
+            kv = caches[cache]
+            impl.forward(layer, q_buf, k_buf, v_buf, kv.view(torch.float8_e4m3fn) if cache == "fp8" else kv, md, output=out)
+
+    def check(i, seq_lens, q, ks, vs, slots, how):
+        B = len(seq_lens)
+        torch.cuda.synchronize()
+        ref16 = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], np.arange(B + 1), seq_lens, scale, "causal", 0, 0, 0)
+        seen = lambda x, sc: orc.bf16_round(orc.fp8_cache_roundtrip(x, sc).astype(np.float32))  # noqa: E731
+        ref8 = orc.varlen_gqa_attention(q, lambda b: seen(ks[b], k_scale), lambda b: seen(vs[b], v_scale), np.arange(B + 1),
+                                        seq_lens, scale, "causal", 0, 0, 0)
+        for (name, impl, cache), out in zip(layers, outs):
+            got = out.float().cpu().numpy().reshape(cap, H, D)
+            assert_close(got[:B], ref8 if cache == "fp8" else ref16, f"decode step {how}: {name}", out16=True, info=(i, seq_lens))
+            assert np.all(got[B:] == 0.0), (name, "padding rows must be left alone")
+        # the step's rows reached the cache through the same launches
+        flat = caches["bf16"].view(2, nblk_cap * page, Hkv, D)
+        sd = torch.from_numpy(slots[:B]).to(DEV)
+        assert torch.equal(flat[0][sd], k_buf[:B].view(B, Hkv, D)) and torch.equal(flat[1][sd], v_buf[:B].view(B, Hkv, D))
+        want8 = orc.fp8_e4m3fn_encode(k_buf[:B].float().cpu().numpy().reshape(B, Hkv, D) / np.float32(k_scale))
+        assert np.array_equal(caches["fp8"].view(2, nblk_cap * page, Hkv, D)[0][sd].cpu().numpy(), want8)
+
+    # eager first (also the warm-up the runner does ahead of a capture)
+    data = load_step(0, steps[0])
+    md_eager = builder.build(0, common(max(steps[0])))
+    assert md_eager.uniform_decode and not md_eager.capturing
+    run_layers(md_eager)
+    check(0, steps[0], *data, "eager")
+    for o in outs:
+        o.zero_()
+    md = builder.build_for_cudagraph_capture(common(max_len))
+    assert md.capturing and md.uniform_decode
+    run_layers(md)  # warm-up with the capture's own metadata (the work area of this batch size is made here)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run_layers(md)
+    for i, seq_lens in enumerate(steps):
+        for o in outs:
+            o.zero_()
+        data = load_step(i, seq_lens)
+        graph.replay()
+        check(i, seq_lens, *data, "replayed")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

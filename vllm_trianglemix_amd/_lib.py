@@ -14,7 +14,7 @@ TMX_OK, TMX_ERR_INVALID_ARG, TMX_ERR_UNSUPPORTED, TMX_ERR_HIP, TMX_ERR_CAPACITY 
 TMX_F32, TMX_BF16, TMX_F16, TMX_FP8_E4M3 = range(4)
 TMX_MODE_NONE, TMX_MODE_CAUSAL, TMX_MODE_TRIANGLE = range(3)
 TMX_MASK_STREAMING, TMX_MASK_LAST, TMX_MASK_MIDDLE, TMX_MASK_TRIANGLE, TMX_MASK_DENSE = range(5)
-TMX_ABI_VERSION = 4
+TMX_ABI_VERSION = 5
 
 # every symbol include/trianglemix_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = (
     "tmx_replace_neg_inf", "tmx_index_sizes", "tmx_build_block_index", "tmx_attention", "tmx_reshape_and_cache",
     "tmx_reshape_and_cache_fp8", "tmx_gather_dequant_kv_fp8", "tmx_suggest_chunk_tiles",
     "tmx_attention_static_ws", "tmx_static_workspace_bytes", "tmx_static_workspace_warmup", "tmx_eager_attention_f32",
+    "tmx_decode_attention", "tmx_decode_workspace_rows",
 )
 
 
@@ -73,6 +74,23 @@ class AttentionArgs(Structure):
         ("flags", c_uint32), ("reserved", c_uint32),
     ]
 
+class DecodeArgs(Structure):
+    _fields_ = [
+        ("struct_size", c_uint32), ("io_dtype", c_int32), ("out_dtype", c_int32), ("scale", c_float),
+        ("batch", c_int32), ("num_heads", c_int32), ("num_kv_heads", c_int32), ("head_dim", c_int32),
+        ("out", c_void_p), ("out_stride_t", c_int64), ("out_stride_h", c_int64),
+        ("q", c_void_p), ("q_stride_t", c_int64), ("q_stride_h", c_int64),
+        ("k", c_void_p), ("v", c_void_p),
+        ("kv_stride_page", c_int64), ("kv_stride_t", c_int64), ("kv_stride_h", c_int64),
+        ("block_table", c_void_p), ("block_table_stride", c_int64), ("page_size", c_int32),
+        ("kv_dtype", c_int32), ("k_scale", c_float), ("v_scale", c_float),
+        ("k_new", c_void_p), ("v_new", c_void_p), ("new_stride_t", c_int64), ("new_stride_h", c_int64),
+        ("cache_slots", c_void_p), ("seq_lens", c_void_p),
+        ("partial_o", c_void_p), ("partial_ml", c_void_p), ("workspace_rows", c_int64),
+        ("flags", c_uint32), ("reserved", c_uint32),
+    ]
+
+
 TMX_ATTN_SKIP_COMBINE, TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES, TMX_ATTN_NO_BAND, TMX_ATTN_NO_DENSE = 1, 2, 4, 8, 16
 TMX_ATTN_NO_DECODE, TMX_ATTN_DECODE_ONLY, TMX_ATTN_DECODE_VALU = 32, 64, 128
 
@@ -110,6 +128,9 @@ def load() -> ctypes.CDLL:
     lib.tmx_static_workspace_bytes.argtypes = []
     lib.tmx_static_workspace_bytes.restype = ctypes.c_size_t
     lib.tmx_static_workspace_warmup.argtypes = []
+    lib.tmx_decode_attention.argtypes = [POINTER(DecodeArgs), c_void_p]
+    lib.tmx_decode_workspace_rows.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.tmx_decode_workspace_rows.restype = c_int64
     lib.tmx_reshape_and_cache.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                           c_int64, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p]

@@ -94,6 +94,11 @@ class TriangleMixAttentionMetadata:
     # the trailing dense rows and the length gate refer to the whole prompt, as in a one-step prefill.
     prompt_lens: Optional[torch.Tensor] = None       # int32 [B], device
     prompt_lens_cpu: Optional[np.ndarray] = None     # int32 [B]
+    # A step of one-row requests (uniform single-token decode): the layers may take the launch whose shape depends on
+    # the batch size only and that reads seq_lens / block table / slot mapping on the device.
+    uniform_decode: bool = False
+    capturing: bool = False
+    builder: Optional["TriangleMixMetadataBuilder"] = field(default=None, repr=False)
     _indices: Dict[Tuple, "ops.BlockIndex"] = field(default_factory=dict, repr=False)
     _workspaces: Dict[Tuple, tuple] = field(default_factory=dict, repr=False)
 
@@ -162,6 +167,9 @@ class TriangleMixAttentionMetadata:
 #            rocm_attn.py:345-354).
 _CACHE_WRITE_MODE = os.environ.get("TRIANGLEMIX_CACHE_WRITE", "fused")
 _CACHE_WRITE_STREAM = os.environ.get("TRIANGLEMIX_CACHE_WRITE_STREAM", "1") != "0"  # "stream" mode's switch
+# Steps of one-row requests take the launch with a fixed shape (no index, nothing sized on the host from the
+# lengths; the only form that replays under a graph).  "0": they go through the block index like every other step.
+_DECODE_FIXED = os.environ.get("TRIANGLEMIX_DECODE_FIXED", "1") != "0"
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -188,9 +196,11 @@ def _step_flags(m: "TriangleMixAttentionMetadata") -> int:
 
 class TriangleMixMetadataBuilder(_BuilderBase):
     """``AttentionMetadataBuilder`` subclass (utils.py:232-341; rocm_attn.py:60-135)."""
-    # the index depends on the batch and is rebuilt every step on the host side of the step: no graph replay
-    # (utils.py:215-239; read as ``.value`` at gpu_model_runner.py:3617)
-    cudagraph_support: ClassVar[AttentionCGSupport] = AttentionCGSupport.NEVER
+    # Steps of one-row requests replay under a graph: their launch (tmx_decode_attention) depends on the batch size
+    # only, and reads seq_lens / block table / slot mapping from the runner's persistent buffers.  Steps with prompts need the block index, whose size follows the batch: built every step
+    # on the host side, so they stay outside graphs (utils.py:215-229; read as ``.value`` at
+    # gpu_model_runner.py:3612-3619; the reference's own ROCm backend declares ALWAYS, rocm_attn.py:63).
+    cudagraph_support: ClassVar[AttentionCGSupport] = AttentionCGSupport.UNIFORM_SINGLE_TOKEN_DECODE
     reorder_batch_threshold: Optional[int] = None
 
     def __init__(self, kv_cache_spec, layer_names: List[str], vllm_config, device: torch.device):
@@ -199,6 +209,16 @@ class TriangleMixMetadataBuilder(_BuilderBase):
         self.vllm_config = vllm_config
         self.device = device
         self.block_size = int(kv_cache_spec.block_size)
+        self._decode_ws: Dict[Tuple, tuple] = {}
+
+    def decode_workspace(self, batch: int, num_heads: int, num_kv_heads: int, head_size: int, fp8: bool) -> tuple:
+        """Work area of the fixed-shape decode launch for a batch size, held for the builder's life: a captured
+        launch replays with these pointers (a few MB per batch size: (512 / K/V head chunks + batch) x heads rows)."""
+        key = (batch, num_heads, num_kv_heads, head_size, fp8)
+        ws = self._decode_ws.get(key)
+        if ws is None:
+            ws = self._decode_ws[key] = ops.decode_workspace(batch, num_heads, num_kv_heads, head_size, self.device, fp8)
+        return ws
 
     def build(self, common_prefix_len: int, common_attn_metadata, fast_build: bool = False
               ) -> TriangleMixAttentionMetadata:
@@ -216,15 +236,29 @@ class TriangleMixMetadataBuilder(_BuilderBase):
         if prompt_cpu is not None:
             prompt_cpu = host_i32(prompt_cpu)
             prompt_dev = torch.from_numpy(prompt_cpu).to(m.seq_lens.device, non_blocking=True)
-        return TriangleMixAttentionMetadata(
+        md = TriangleMixAttentionMetadata(
             num_actual_tokens=int(m.num_actual_tokens), max_query_len=int(m.max_query_len),
             query_start_loc=m.query_start_loc, max_seq_len=int(m.max_seq_len), seq_lens=m.seq_lens,
             block_table=m.block_table_tensor, slot_mapping=m.slot_mapping,
             query_start_loc_cpu=host_i32(m.query_start_loc_cpu), seq_lens_cpu=host_i32(m.seq_lens_cpu),
-            page_size=self.block_size, prompt_lens=prompt_dev, prompt_lens_cpu=prompt_cpu)
+            page_size=self.block_size, prompt_lens=prompt_dev, prompt_lens_cpu=prompt_cpu, builder=self)
+        # uniform single-token decode: one query row per request, row b = request b
+        if (_DECODE_FIXED and md.max_query_len == 1 and md.num_actual_tokens == md.seq_lens_cpu.shape[0] > 0
+                and md.query_start_loc_cpu.shape[0] == md.num_actual_tokens + 1
+                and int(md.query_start_loc_cpu[-1]) == md.num_actual_tokens):
+            md.uniform_decode = True
+        return md
 
     def build_for_cudagraph_capture(self, common_attn_metadata) -> TriangleMixAttentionMetadata:
-        return self.build(common_prefix_len=0, common_attn_metadata=common_attn_metadata)
+        """Metadata of the step a graph is captured from (utils.py:296-303; the runner calls it with a uniform
+        decode batch, gpu_model_runner.py:3612-3619 having checked ``cudagraph_support``).  The layers' launches then
+        depend on the batch size alone, so replays serve any later lengths."""
+        md = self.build(common_prefix_len=0, common_attn_metadata=common_attn_metadata)
+        if not md.uniform_decode:
+            raise NotImplementedError("TriangleMix steps replay under a graph only as uniform single-token decode "
+                                      "(AttentionCGSupport.UNIFORM_SINGLE_TOKEN_DECODE)")
+        md.capturing = True
+        return md
 
     def use_cascade_attention(self, *args, **kwargs) -> bool:
         return False
@@ -353,6 +387,11 @@ class TriangleMixAttentionImpl(_ImplBase):
             return self._forward_fp8_cache(layer, q, key, value, key_cache, value_cache, m, output)
         writes_cache = self.kv_sharing_target_layer_name is None and key is not None and value is not None
         out = output.view(-1, self.num_heads, self.head_size)[:n_tok]
+        if m.uniform_decode and self._decode_fixed_ok():
+            return self._forward_decode_fixed(q, key, value, key_cache, value_cache, m, out, output, writes_cache)
+        if m.capturing:
+            raise NotImplementedError("this layer's shape has no decode launch that replays under a graph (head size "
+                                      "128, query-head groups that are multiples of 4, num_last_tokens >= 2)")
         mode = "triangle" if self.use_triangle else "causal"
         pattern = self.pattern if self.use_triangle else (0, 0, 0)
         tri_min_len = self.tri_min_len if self.use_triangle else 0
@@ -392,6 +431,33 @@ class TriangleMixAttentionImpl(_ImplBase):
                       block_table=m.block_table, workspace=ws, flags=_step_flags(m))
         return output
 
+    def _decode_fixed_ok(self) -> bool:
+        """The fixed-shape decode launch covers head size 128 and query-head groups that are multiples of 4; a decode
+        row attends to all of its keys in a causal layer, and in a triangle layer when it lies among the trailing
+        dense rows, i.e. with ``num_last_tokens >= 2`` (N - i = 1 < last, trianglemix_attention.py:126-129)."""
+        return (self.head_size == 128 and (self.num_heads // self.num_kv_heads) % 4 == 0
+                and (not self.use_triangle or self.pattern[2] >= 2))
+
+    def _forward_decode_fixed(self, q, key, value, key_cache, value_cache, m, out, output, writes_cache,
+                              k_scale: float = 1.0, v_scale: float = 1.0):
+        """A step of one-row requests through ``tmx_decode_attention``: no index, nothing derived on the host from the
+        requests' lengths -- the call replays under a graph with whatever ``seq_lens`` / ``block_table`` /
+        ``slot_mapping`` hold by then.  A 16-bit cache gets the step's rows from the same launch."""
+        n_tok = m.num_actual_tokens
+        fp8 = self.fp8_cache
+        if m.builder is not None:
+            ws = m.builder.decode_workspace(n_tok, self.num_heads, self.num_kv_heads, self.head_size, fp8)
+        else:
+            ws = ops.decode_workspace(n_tok, self.num_heads, self.num_kv_heads, self.head_size, q.device, fp8)
+        k_rows = v_rows = slots = None
+        if writes_cache and not fp8:
+            k_rows = key[:n_tok].view(n_tok, self.num_kv_heads, self.head_size)
+            v_rows = value[:n_tok].view(n_tok, self.num_kv_heads, self.head_size)
+            slots = m.slot_mapping[:n_tok]
+        ops.decode_attention(q, key_cache, value_cache, out, m.block_table, m.seq_lens, self.scale, ws,
+                             k_scale=k_scale, v_scale=v_scale, k_new=k_rows, v_new=v_rows, cache_slots=slots)
+        return output
+
     def _forward_fp8_cache(self, layer, q, key, value, key_cache, value_cache, m, output):
         """kv_cache_dtype "fp8" (rocm_attn.py:356-358, 421-422): the step's rows are written as
         fp8(x / scale); the attention then reads what the cache holds, times the scale.  The query
@@ -401,9 +467,15 @@ class TriangleMixAttentionImpl(_ImplBase):
         k_scale = float(getattr(layer, "_k_scale_float", 1.0))
         v_scale = float(getattr(layer, "_v_scale_float", 1.0))
         if self.kv_sharing_target_layer_name is None and key is not None and value is not None:
-            ops.reshape_and_cache_fp8(key[:n_tok], value[:n_tok], key_cache, value_cache, m.slot_mapping[:n_tok],
-                                      k_scale, v_scale)
+            ops.reshape_and_cache_fp8(key[:n_tok].view(n_tok, self.num_kv_heads, self.head_size),
+                                      value[:n_tok].view(n_tok, self.num_kv_heads, self.head_size), key_cache, value_cache,
+                                      m.slot_mapping[:n_tok], k_scale, v_scale)
         out = output.view(-1, self.num_heads, self.head_size)[:n_tok]
+        if m.uniform_decode and self._decode_fixed_ok():
+            return self._forward_decode_fixed(q, key, value, key_cache, value_cache, m, out, output, False,
+                                              k_scale=k_scale, v_scale=v_scale)
+        if m.capturing:
+            raise NotImplementedError("this layer's shape has no decode launch that replays under a graph")
         mode = "triangle" if self.use_triangle else "causal"
         pattern = self.pattern if self.use_triangle else (0, 0, 0)
         tri_min_len = self.tri_min_len if self.use_triangle else 0

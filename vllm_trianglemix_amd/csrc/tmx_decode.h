@@ -54,8 +54,19 @@ struct DecodeParams {
   float scale_log2;
   int kv_fp8;  // K/V are an fp8 (e4m3fn) paged cache: strides in bytes, value = fp8 x scale
   float k_scale, v_scale;
+  // Fixed-grid form (tmx_decode_attention): no index.  The step's pieces are laid out on the device, by every
+  // workgroup for itself, from seq_lens alone: T = all requests' 32-key tiles, piece length P = max(8, ceil(T *
+  // plan_units / plan_slots)) tiles (one piece per workgroup slot of the chip), request b has ceil(tiles_b / P)
+  // pieces, and the pieces of all requests are numbered in request order.  Workgroup (piece w, K/V head chunk)
+  // of the grid's pieces_cap x Y finds the request that owns piece w; a request with more than one piece leaves
+  // partial results in slot w (one row each: block_m = 1) for the merge launch.  Since sum_b ceil(tiles_b / P) <=
+  // T / P + batch <= plan_slots / plan_units + batch, pieces_cap = that bound covers every step of the batch size.
+  const int32_t* seq_lens;
+  int pieces_cap, plan_units, plan_slots;
 };
 
 int launch_decode(const DecodeParams& p, bool bf16, bool paged, hipStream_t s);
+// the fixed-grid form: batch x pieces_cap x Y workgroups, then the merge launch when pieces_cap > 1
+int launch_decode_fixed(const DecodeParams& p, bool bf16, int batch, hipStream_t s);
 
 }  // namespace tmx

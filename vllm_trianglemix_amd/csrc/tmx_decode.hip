@@ -19,6 +19,7 @@
 //   once to the 16-bit type (vllm/v1/attention/backends/rocm_attn.py:421-422).
 //   At the end the 16 partial results of a workgroup (4 waves x 4 lane groups) merge through LDS into the
 //   output row, or into the piece's partial slot for the combine pass of the work-list kernel's launch.
+#include <atomic>
 #include <type_traits>
 
 #include "tmx_common.h"
@@ -80,7 +81,80 @@ __device__ __forceinline__ void dc_unpack(uint32_t w, float& lo, float& hi) {
   }
 }
 
-template <bool BF16, bool PAGED, bool KV8, bool UNIT, int HW, bool MPV>
+// ---- the fixed-grid form's plan (see DecodeParams): computed by every workgroup for itself ----
+// Sum of v over the NT threads of the workgroup (sm: NT / 64 ints of LDS, free again on return).
+template <int NT>
+__device__ __forceinline__ int dc_block_sum(int v, int* sm, int tid) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  if ((tid & 63) == 0) sm[tid >> 6] = v;
+  __syncthreads();
+  int tot = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) tot += sm[w];
+  __syncthreads();
+  return tot;
+}
+__device__ __forceinline__ int dc_tiles_of(int n) { return n > 0 ? (n + kBlockN - 1) / kBlockN : 0; }
+// Piece length of the step: one piece per workgroup slot of the chip, at least 8 tiles.
+__device__ __forceinline__ int dc_piece_len(long long total_tiles, int units, int slots) {
+  const long long c = (total_tiles * units + slots - 1) / slots;
+  return c < 8 ? 8 : (int)c;
+}
+struct DcPiece {
+  int b, n, tile0, ntiles, pieces;  // request (-1: no such piece), its keys, the piece's tiles, the request's piece count
+};
+// The request that owns piece w of the step, and which of its tiles the piece covers.  All NT threads call it.
+template <int NT>
+__device__ __forceinline__ DcPiece dc_find_piece(const int32_t* seq_lens, int batch, int units, int slots, int w, int* sm, int tid) {
+  const int per = (batch + NT - 1) / NT;  // requests per thread, a contiguous run
+  const int j0 = imin(batch, tid * per), j1 = imin(batch, j0 + per);
+  int mine = 0;
+  for (int j = j0; j < j1; ++j) mine += dc_tiles_of(seq_lens[j]);
+  const int total = dc_block_sum<NT>(mine, sm, tid);
+  const int P = dc_piece_len(total, units, slots);
+  int cnt = 0;
+  for (int j = j0; j < j1; ++j) cnt += (dc_tiles_of(seq_lens[j]) + P - 1) / P;
+  // exclusive prefix of cnt over the threads: inside the wave by shuffles, across waves through LDS
+  int inc = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(inc, d, 64);
+    if ((tid & 63) >= d) inc += up;
+  }
+  if ((tid & 63) == 63) sm[tid >> 6] = inc;
+  if (tid == 0) sm[NT / 64] = -1;  // the answer's slot: (request, first piece of the request)
+  __syncthreads();
+  int start = inc - cnt;
+  for (int x = 0; x < (tid >> 6); ++x) start += sm[x];
+  if (w >= start && w < start + cnt) {
+    int first = start;
+    for (int j = j0; j < j1; ++j) {
+      const int pj = (dc_tiles_of(seq_lens[j]) + P - 1) / P;
+      if (w < first + pj) {
+        sm[NT / 64] = j;
+        sm[NT / 64 + 1] = first;
+        break;
+      }
+      first += pj;
+    }
+  }
+  __syncthreads();
+  DcPiece r;
+  r.b = sm[NT / 64];
+  if (r.b < 0) return r;
+  r.n = seq_lens[r.b];
+  const int tiles = dc_tiles_of(r.n);
+  r.pieces = (tiles + P - 1) / P;
+  r.tile0 = (w - sm[NT / 64 + 1]) * P;
+  r.ntiles = imin(P, tiles - r.tile0);
+  return r;
+}
+
+// FIXED: the grid does not come from an index.  Workgroup (request, piece, K/V head chunk) derives its key range
+// from seq_lens on the device, so the launch has the same shape whatever the requests' lengths are (a step
+// captured in a HIP graph replays with other lengths and block tables).
+template <bool BF16, bool PAGED, bool KV8, bool UNIT, int HW, bool MPV, bool FIXED = false>
 __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
   constexpr int D = 128;
   constexpr int KVB = KV8 ? 1 : 2;
@@ -122,18 +196,35 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
     }
   }
 
-  const int item = (int)blockIdx.x / p.Y, kvc = (int)blockIdx.x % p.Y;
-  const dc_i32x4 a0 = dcs(reinterpret_cast<const dc_i32x4*>(p.items) + 2ll * item);
-  const dc_i32x4 a1 = dcs(reinterpret_cast<const dc_i32x4*>(p.items) + 2ll * item + 1);
-  // a0 = (q-block, first entry of col_idx, tiles, partial slot), a1 = (request, query row, position, keys)
-  const int b = a1.x, q_tok = a1.y, pos = a1.z, n = a1.w;
-  {
-    const int q_len = dcs(p.cu_q + b + 1) - dcs(p.cu_q + b);
-    const int nf = p.full_lens != nullptr ? imax(n, dcs(p.full_lens + b)) : n;
-    if (!decode_row(p.mode, p.last, p.tri_min_len, q_len, pos, nf)) return;  // the work-list kernel computes it
+  int kvc, b, q_tok, pos, n, ntiles, slot, tile0;
+  if constexpr (FIXED) {
+    __shared__ int plan_sm[4 + 2];
+    const int w = (int)blockIdx.x / p.Y;
+    kvc = (int)blockIdx.x - w * p.Y;
+    const DcPiece dp = dc_find_piece<256>(p.seq_lens, p.total_q, p.plan_units, p.plan_slots, w, plan_sm, tid);
+    if (dp.b < 0) return;  // fewer pieces in this step than the grid provides for
+    b = dp.b;
+    n = dp.n;
+    tile0 = dp.tile0;
+    ntiles = dp.ntiles;
+    slot = dp.pieces > 1 ? w : -1;  // one piece: the output row is written straight away
+    q_tok = b;
+    pos = n - 1;
+  } else {
+    const int item = (int)blockIdx.x / p.Y;
+    kvc = (int)blockIdx.x % p.Y;
+    const dc_i32x4 a0 = dcs(reinterpret_cast<const dc_i32x4*>(p.items) + 2ll * item);
+    const dc_i32x4 a1 = dcs(reinterpret_cast<const dc_i32x4*>(p.items) + 2ll * item + 1);
+    // a0 = (q-block, first entry of col_idx, tiles, partial slot), a1 = (request, query row, position, keys)
+    b = a1.x, q_tok = a1.y, pos = a1.z, n = a1.w;
+    {
+      const int q_len = dcs(p.cu_q + b + 1) - dcs(p.cu_q + b);
+      const int nf = p.full_lens != nullptr ? imax(n, dcs(p.full_lens + b)) : n;
+      if (!decode_row(p.mode, p.last, p.tri_min_len, q_len, pos, nf)) return;  // the work-list kernel computes it
+    }
+    ntiles = a0.z, slot = a0.w;
+    tile0 = ntiles > 0 ? dcs(p.col_idx + a0.y) : 0;  // a dense row's tiles are consecutive
   }
-  const int ntiles = a0.z, slot = a0.w;
-  const int tile0 = ntiles > 0 ? dcs(p.col_idx + a0.y) : 0;  // a dense row's tiles are consecutive
   const int chunks = p.G / HW;
   const int kvh = kvc / chunks;
   const int head0 = kvh * p.G + (kvc - kvh * chunks) * HW;
@@ -473,6 +564,73 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
   }
 }
 
+// Merge launch of the fixed-grid form: one workgroup per (request, head), one thread per column.  A request with
+// one piece wrote its output row itself; the others left (max, sum) and an unnormalised row per piece.
+template <int D>
+__global__ __launch_bounds__(D) void decode_merge_kernel(const DecodeParams p) {
+  __shared__ int sm[D / 64];
+  const int b = (int)blockIdx.x, head = (int)blockIdx.y, d = (int)threadIdx.x;
+  const int batch = p.total_q;
+  const int per = (batch + D - 1) / D;
+  const int j0 = imin(batch, d * per), j1 = imin(batch, j0 + per);
+  int mine = 0;
+  for (int j = j0; j < j1; ++j) mine += dc_tiles_of(p.seq_lens[j]);
+  const int total = dc_block_sum<D>(mine, sm, d);
+  const int P = dc_piece_len(total, p.plan_units, p.plan_slots);
+  const int np = (dc_tiles_of(p.seq_lens[b]) + P - 1) / P;
+  if (np <= 1) return;  // (uniform over the workgroup)
+  int before = 0;
+  for (int j = j0; j < imin(j1, b); ++j) before += (dc_tiles_of(p.seq_lens[j]) + P - 1) / P;
+  const int first = dc_block_sum<D>(before, sm, d);
+  const long long row0 = (long long)first * p.H + head;  // piece x of the request: row0 + x * H
+  float M = kDcMinusBig;
+  for (int x = 0; x < np; ++x) M = fmaxf(M, p.partial_ml[2 * (row0 + (long long)x * p.H)]);
+  float L = 0.f, o = 0.f;
+  for (int x = 0; x < np; ++x) {
+    const long long row = row0 + (long long)x * p.H;
+    const float wgt = __builtin_amdgcn_exp2f(p.partial_ml[2 * row] - M);
+    L += wgt * p.partial_ml[2 * row + 1];
+    o += wgt * p.partial_o[row * D + d];
+  }
+  const float r = o / L;
+  const long long off = (long long)b * p.out_stride_t + (long long)head * p.out_stride_h + d;
+  if (p.out_dtype == TMX_F32) reinterpret_cast<float*>(p.out)[off] = r;
+  else if (p.out_dtype == TMX_BF16) reinterpret_cast<uint16_t*>(p.out)[off] = (uint16_t)(dc_pack<true>(r, 0.f) & 0xffffu);
+  else reinterpret_cast<uint16_t*>(p.out)[off] = (uint16_t)(dc_pack<false>(r, 0.f) & 0xffffu);
+}
+
+int launch_decode_fixed(const DecodeParams& p, bool bf16, int batch, hipStream_t s) {
+  const long long grid = (long long)p.pieces_cap * p.Y;
+  if (grid <= 0 || batch <= 0) return TMX_OK;
+  TMX_CHECK_SUPPORTED(grid < (1ll << 31), "decode kernel: too many workgroups");
+  const unsigned gsz = (unsigned)grid;
+#define TMX_DECODE_FIXED(BF, K8, UN)                                                        \
+  do {                                                                                      \
+    if (p.hw == 8) decode_kernel<BF, true, K8, UN, 8, true, true><<<gsz, 256, 0, s>>>(p);   \
+    else decode_kernel<BF, true, K8, UN, 4, true, true><<<gsz, 256, 0, s>>>(p);             \
+  } while (0)
+  if (p.kv_fp8) {
+    const bool unit = p.k_scale == 1.0f && p.v_scale == 1.0f;
+    if (unit) {
+      if (bf16) TMX_DECODE_FIXED(true, true, true);
+      else TMX_DECODE_FIXED(false, true, true);
+    } else {
+      if (bf16) TMX_DECODE_FIXED(true, true, false);
+      else TMX_DECODE_FIXED(false, true, false);
+    }
+  } else if (bf16) {
+    TMX_DECODE_FIXED(true, false, false);
+  } else {
+    TMX_DECODE_FIXED(false, false, false);
+  }
+#undef TMX_DECODE_FIXED
+  TMX_CHECK_HIP(hipGetLastError());
+  // (a step whose requests all fit one piece finds nothing to merge: its workgroups return after the plan)
+  decode_merge_kernel<128><<<dim3((unsigned)batch, (unsigned)p.H), 128, 0, s>>>(p);
+  TMX_CHECK_HIP(hipGetLastError());
+  return TMX_OK;
+}
+
 int launch_decode(const DecodeParams& p, bool bf16, bool paged, hipStream_t s) {
   const long long grid = (long long)p.num_items * p.Y;
   if (grid <= 0) return TMX_OK;
@@ -512,3 +670,161 @@ int launch_decode(const DecodeParams& p, bool bf16, bool paged, hipStream_t s) {
 }
 
 }  // namespace tmx
+
+// ---------------------------------------------------------------------------------------------------
+// tmx_decode_attention: a step of one-row requests with no index and nothing sized on the host from the
+// requests' lengths (see include/trianglemix_hip.h).
+namespace tmx {
+
+static int decode_cus(int* out) {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  TMX_CHECK_HIP(hipGetDevice(&dev));
+  int cus = (dev >= 0 && dev < 64) ? cache[dev].load(std::memory_order_relaxed) : 0;
+  if (cus == 0) {
+    TMX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
+  }
+  *out = cus;
+  return TMX_OK;
+}
+
+static bool dc_aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
+
+}  // namespace tmx
+
+namespace tmx {
+// (K/V head chunks the plan counts per piece, workgroup slots of the chip): 4 query heads per unit out of a 16-bit
+// cache; 8 when the group allows out of an fp8 cache (half the bytes per key, so twice the pieces keep the chip busy
+// -- the split measured fastest for index-driven decode steps, 64 x 8192: 16 / 2 heads 54 us in 64-tile pieces against
+// 78 us in 128-tile ones)
+static void decode_plan_shape(int num_heads, int num_kv_heads, bool fp8, int num_cus, int* units, int* slots) {
+  const int G = num_heads / num_kv_heads;
+  const int hw = (fp8 && G % 8 == 0) ? 8 : 4;
+  *units = num_kv_heads * (G / hw > 0 ? G / hw : 1);
+  *slots = 2 * num_cus;  // two workgroups are resident per CU
+}
+}  // namespace tmx
+
+extern "C" int64_t tmx_decode_workspace_rows(int batch, int num_heads, int num_kv_heads, int kv_dtype, int num_cus) {
+  using namespace tmx;
+  if (batch <= 0 || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0) return 0;
+  if (num_cus <= 0 && decode_cus(&num_cus) != TMX_OK) return -1;
+  int units = 1, slots = 1;
+  decode_plan_shape(num_heads, num_kv_heads, kv_dtype == TMX_FP8_E4M3, num_cus, &units, &slots);
+  const long long pieces = (slots + units - 1) / units + batch;  // bound of the step's pieces (see DecodeParams)
+  return (int64_t)pieces * num_heads;
+}
+
+extern "C" int tmx_decode_attention(const tmx_decode_args_t* a, void* stream) {
+  using namespace tmx;
+  TMX_CHECK_ARG(a != nullptr, "tmx_decode_attention: args is NULL");
+  TMX_CHECK_ARG(a->struct_size == sizeof(tmx_decode_args_t), "tmx_decode_attention: struct_size %u != %zu (ABI mismatch)",
+                a->struct_size, sizeof(tmx_decode_args_t));
+  TMX_CHECK_SUPPORTED(a->io_dtype == TMX_BF16 || a->io_dtype == TMX_F16,
+                      "tmx_decode_attention: q dtype %d not supported (bf16 and fp16 are)", a->io_dtype);
+  TMX_CHECK_SUPPORTED(a->out_dtype == a->io_dtype || a->out_dtype == TMX_F32,
+                      "tmx_decode_attention: out dtype %d must equal the input dtype or be fp32", a->out_dtype);
+  TMX_CHECK_ARG(a->num_heads > 0 && a->num_kv_heads > 0 && a->num_heads % a->num_kv_heads == 0,
+                "tmx_decode_attention: num_heads %d must be a positive multiple of num_kv_heads %d", a->num_heads,
+                a->num_kv_heads);
+  const int G = a->num_heads / a->num_kv_heads;
+  TMX_CHECK_SUPPORTED(a->head_dim == 128 && G % 4 == 0,
+                      "tmx_decode_attention: head_dim %d / %d query heads per K/V head not covered (head size 128, "
+                      "groups that are multiples of 4; other shapes: tmx_attention with an index)", a->head_dim, G);
+  TMX_CHECK_ARG(a->scale > 0.f && a->scale < 3.0e38f, "tmx_decode_attention: scale %g must be positive and finite",
+                (double)a->scale);
+  TMX_CHECK_ARG(a->batch >= 0, "tmx_decode_attention: negative batch");
+  if (a->batch == 0) return TMX_OK;
+  TMX_CHECK_ARG(a->q && a->out && a->k && a->v && a->seq_lens && a->block_table, "tmx_decode_attention: NULL tensor");
+  TMX_CHECK_SUPPORTED(a->page_size >= 16 && (a->page_size & (a->page_size - 1)) == 0,
+                      "tmx_decode_attention: page_size %d not supported (powers of two >= 16 are)", a->page_size);
+  TMX_CHECK_ARG(dc_aligned16(a->q) && dc_aligned16(a->k) && dc_aligned16(a->v) && dc_aligned16(a->out),
+                "tmx_decode_attention: q / k / v / out must be 16-byte aligned");
+  const int64_t lim = 0x7FFFFFFF;
+  TMX_CHECK_SUPPORTED(a->q_stride_t >= 0 && a->q_stride_t <= lim && a->q_stride_h >= 0 && a->q_stride_h <= lim &&
+                          a->out_stride_t >= 0 && a->out_stride_t <= lim && a->out_stride_h >= 0 && a->out_stride_h <= lim &&
+                          a->kv_stride_page >= 0 && a->kv_stride_page <= lim && a->kv_stride_t >= 0 &&
+                          a->kv_stride_t < (1ll << 24) && a->kv_stride_h >= 0 && a->kv_stride_h <= lim &&
+                          a->block_table_stride >= 0 && a->block_table_stride <= lim,
+                      "tmx_decode_attention: strides must be non-negative and below 2^31 elements (K/V rows: 2^24)");
+  TMX_CHECK_ARG(a->q_stride_t % 8 == 0 && a->q_stride_h % 8 == 0 && a->out_stride_t % 2 == 0 && a->out_stride_h % 2 == 0 &&
+                    a->kv_stride_t % 8 == 0 && a->kv_stride_h % 8 == 0 && a->kv_stride_page % 8 == 0,
+                "tmx_decode_attention: strides must be multiples of 8 elements");
+  const bool fp8 = a->kv_dtype == TMX_FP8_E4M3;
+  TMX_CHECK_SUPPORTED(a->kv_dtype == 0 || a->kv_dtype == a->io_dtype || fp8,
+                      "tmx_decode_attention: kv_dtype %d not supported (0 / the q dtype, or TMX_FP8_E4M3)", a->kv_dtype);
+  if (fp8) {
+    TMX_CHECK_ARG(a->k_scale > 0.f && a->v_scale > 0.f && a->k_scale < 3.0e38f && a->v_scale < 3.0e38f,
+                  "tmx_decode_attention: k_scale / v_scale must be positive and finite");
+    TMX_CHECK_ARG(a->kv_stride_t % 16 == 0 && a->kv_stride_h % 16 == 0 && a->kv_stride_page % 16 == 0,
+                  "tmx_decode_attention: fp8 cache strides must be multiples of 16 bytes");
+  }
+  const bool two_src = a->k_new != nullptr || a->v_new != nullptr;
+  if (two_src) {
+    TMX_CHECK_ARG(a->k_new != nullptr && a->v_new != nullptr, "tmx_decode_attention: k_new and v_new go together");
+    TMX_CHECK_SUPPORTED(!fp8, "tmx_decode_attention: k_new / v_new need a 16-bit cache");
+    TMX_CHECK_ARG(dc_aligned16(a->k_new) && dc_aligned16(a->v_new) && a->new_stride_t % 8 == 0 && a->new_stride_h % 8 == 0 &&
+                      a->new_stride_t >= 0 && a->new_stride_h >= 0 && a->new_stride_t < (1ll << 24) && a->new_stride_h <= lim,
+                  "tmx_decode_attention: k_new / v_new must be 16-byte aligned with strides that are multiples of 8 elements");
+  }
+  TMX_CHECK_ARG(a->cache_slots == nullptr || two_src, "tmx_decode_attention: cache_slots needs k_new / v_new (the rows to store)");
+  int cus = 0;
+  {
+    const int rc = decode_cus(&cus);
+    if (rc != TMX_OK) return rc;
+  }
+  int units = 1, slots = 1;
+  decode_plan_shape(a->num_heads, a->num_kv_heads, fp8, cus, &units, &slots);
+  const long long pieces = (slots + units - 1) / units + a->batch;
+  TMX_CHECK_ARG(a->partial_o != nullptr && a->partial_ml != nullptr && dc_aligned16(a->partial_o),
+                "tmx_decode_attention: the work area is missing (tmx_decode_workspace_rows)");
+  TMX_CHECK_ARG(a->workspace_rows >= pieces * a->num_heads,
+                "tmx_decode_attention: the work area holds %lld rows, this batch size needs %lld (tmx_decode_workspace_rows)",
+                (long long)a->workspace_rows, pieces * a->num_heads);
+  DecodeParams d{};
+  d.q = a->q;
+  d.out = a->out;
+  d.k = a->k;
+  d.v = a->v;
+  d.block_table = a->block_table;
+  d.partial_o = a->partial_o;
+  d.partial_ml = a->partial_ml;
+  d.k_new = a->k_new;
+  d.v_new = a->v_new;
+  d.cache_slots = reinterpret_cast<const long long*>(a->cache_slots);
+  d.new_stride_t = (int)a->new_stride_t;
+  d.new_stride_h = (int)a->new_stride_h;
+  d.total_q = a->batch;
+  d.q_stride_t = (int)a->q_stride_t;
+  d.q_stride_h = (int)a->q_stride_h;
+  d.out_stride_t = (int)a->out_stride_t;
+  d.out_stride_h = (int)a->out_stride_h;
+  d.kv_stride_page = (int)a->kv_stride_page;
+  d.kv_stride_t = (int)a->kv_stride_t;
+  d.kv_stride_h = (int)a->kv_stride_h;
+  d.block_table_stride = (int)a->block_table_stride;
+  d.page_size = a->page_size;
+  d.page_shift = __builtin_ctz(a->page_size);
+  d.H = a->num_heads;
+  d.Hkv = a->num_kv_heads;
+  d.G = G;
+  d.valu_sum = 0;
+  d.hw = G % 8 == 0 ? 8 : 4;  // query heads per workgroup (all of them share the K/V loads), as in tmx_attention
+  d.Y = a->num_kv_heads * (G / d.hw);
+  d.block_m = 1;
+  d.num_items = 0;
+  d.mode = TMX_MODE_CAUSAL;  // the row sits at position n - 1: every key of its sequence is attended
+  d.last = 0;
+  d.tri_min_len = 0;
+  d.out_dtype = a->out_dtype;
+  d.scale_log2 = a->scale * kLog2e;
+  d.kv_fp8 = fp8 ? 1 : 0;
+  d.k_scale = fp8 ? a->k_scale : 1.f;
+  d.v_scale = fp8 ? a->v_scale : 1.f;
+  d.seq_lens = a->seq_lens;
+  d.pieces_cap = (int)pieces;
+  d.plan_units = units;
+  d.plan_slots = slots;
+  return launch_decode_fixed(d, a->io_dtype == TMX_BF16, a->batch, (hipStream_t)stream);
+}

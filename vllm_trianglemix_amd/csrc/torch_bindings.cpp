@@ -280,6 +280,93 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
   check(tmx_attention(&a, stream_of(query)));
 }
 
+// A step of one-row requests with a launch that depends on the batch size alone (tmx_decode_attention): what the
+// backend calls for uniform single-token decode steps, and what replays under a graph.
+void decode_attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const Tensor& value_cache,
+                      const Tensor& block_table, const Tensor& seq_lens, Tensor& partial_o, Tensor& partial_ml,
+                      double scale, const std::optional<Tensor>& k_new, const std::optional<Tensor>& v_new,
+                      const std::optional<Tensor>& cache_slots, double k_scale, double v_scale) {
+  TORCH_CHECK(query.is_cuda(), "trianglemix: query must be on a HIP device (there is no CPU path)");
+  const DeviceGuard guard(query.device());
+  TORCH_CHECK(query.dim() == 3 && out.dim() == 3 && query.sizes() == out.sizes() && query.stride(2) == 1 && out.stride(2) == 1,
+              "trianglemix: query / out must both be [B, H, D] with a contiguous head dimension");
+  TORCH_CHECK(key_cache.dim() == 4 && key_cache.sizes() == value_cache.sizes() && key_cache.strides() == value_cache.strides() &&
+                  key_cache.stride(3) == 1 && key_cache.size(3) == query.size(2),
+              "trianglemix: paged K/V: caches [num_blocks, page_size, Hkv, D] with equal strides");
+  on_gpu(out, query, "out");
+  on_gpu(key_cache, query, "key_cache");
+  on_gpu(value_cache, query, "value_cache");
+  on_gpu(block_table, query, "block_table");
+  on_gpu(seq_lens, query, "seq_lens");
+  on_gpu(partial_o, query, "partial_o");
+  on_gpu(partial_ml, query, "partial_ml");
+  on_gpu(k_new, query, "k_new");
+  on_gpu(v_new, query, "v_new");
+  on_gpu(cache_slots, query, "cache_slots");
+  const int64_t B = query.size(0);
+  TORCH_CHECK(seq_lens.scalar_type() == at::kInt && seq_lens.is_contiguous() && seq_lens.numel() >= B,
+              "trianglemix: seq_lens must be contiguous int32 [B]");
+  TORCH_CHECK(block_table.scalar_type() == at::kInt && block_table.dim() == 2 && block_table.stride(1) == 1 &&
+                  block_table.size(0) >= B,
+              "trianglemix: block_table must be int32 [B, max_blocks] with contiguous rows that cover the batch");
+  const bool fp8 = key_cache.element_size() == 1;
+  TORCH_CHECK(fp8 ? value_cache.element_size() == 1
+                  : (key_cache.scalar_type() == query.scalar_type() && value_cache.scalar_type() == query.scalar_type()),
+              "trianglemix: q, k, v must share a dtype of bfloat16 or float16 (or K/V be an fp8 cache)");
+  TORCH_CHECK(partial_o.scalar_type() == at::kFloat && partial_ml.scalar_type() == at::kFloat && partial_o.is_contiguous() &&
+                  partial_ml.is_contiguous(),
+              "trianglemix: the decode work area is two contiguous float32 tensors");
+  tmx_decode_args_t a{};
+  a.struct_size = sizeof(a);
+  a.io_dtype = dtype_code(query);
+  a.out_dtype = dtype_code(out);
+  a.scale = (float)scale;
+  a.batch = (int32_t)B;
+  a.num_heads = (int32_t)query.size(1);
+  a.num_kv_heads = (int32_t)key_cache.size(2);
+  a.head_dim = (int32_t)query.size(2);
+  a.out = out.data_ptr();
+  a.out_stride_t = out.stride(0);
+  a.out_stride_h = out.stride(1);
+  a.q = query.data_ptr();
+  a.q_stride_t = query.stride(0);
+  a.q_stride_h = query.stride(1);
+  a.k = key_cache.data_ptr();
+  a.v = value_cache.data_ptr();
+  a.kv_stride_page = key_cache.stride(0);
+  a.kv_stride_t = key_cache.stride(1);
+  a.kv_stride_h = key_cache.stride(2);
+  a.block_table = block_table.data_ptr<int32_t>();
+  a.block_table_stride = block_table.stride(0);
+  a.page_size = (int32_t)key_cache.size(1);
+  a.kv_dtype = fp8 ? TMX_FP8_E4M3 : 0;
+  a.k_scale = fp8 ? (float)k_scale : 1.0f;
+  a.v_scale = fp8 ? (float)v_scale : 1.0f;
+  TORCH_CHECK(k_new.has_value() == v_new.has_value(), "trianglemix: k_new and v_new go together");
+  if (k_new.has_value()) {
+    TORCH_CHECK(!fp8 && k_new->dim() == 3 && k_new->sizes() == v_new->sizes() && k_new->strides() == v_new->strides() &&
+                    k_new->stride(2) == 1 && k_new->scalar_type() == query.scalar_type() &&
+                    v_new->scalar_type() == query.scalar_type() && k_new->size(0) >= B &&
+                    k_new->size(1) == key_cache.size(2) && k_new->size(2) == query.size(2),
+                "trianglemix: k_new / v_new must be [B, Hkv, D] rows of the q dtype with equal strides (16-bit cache)");
+    a.k_new = k_new->data_ptr();
+    a.v_new = v_new->data_ptr();
+    a.new_stride_t = k_new->stride(0);
+    a.new_stride_h = k_new->stride(1);
+  }
+  if (cache_slots.has_value()) {
+    TORCH_CHECK(k_new.has_value() && cache_slots->scalar_type() == at::kLong && cache_slots->is_contiguous() &&
+                    cache_slots->numel() >= B,
+                "trianglemix: cache_slots must be contiguous int64 [B] and comes with k_new / v_new");
+    a.cache_slots = cache_slots->data_ptr<int64_t>();
+  }
+  a.seq_lens = seq_lens.data_ptr<int32_t>();
+  a.partial_o = partial_o.data_ptr<float>();
+  a.partial_ml = partial_ml.data_ptr<float>();
+  a.workspace_rows = std::min<int64_t>(partial_o.numel() / query.size(2), partial_ml.numel() / 2);
+  check(tmx_decode_attention(&a, stream_of(query)));
+}
+
 void reshape_and_cache(const Tensor& key, const Tensor& value, Tensor& key_cache, Tensor& value_cache,
                        const Tensor& slot_mapping) {
   const DeviceGuard guard(key.device());
@@ -347,6 +434,10 @@ TORCH_LIBRARY(_trianglemix_C, m) {
         "Tensor? full_lens=None, int flags=0, int nnz_tiles=0, Tensor? k_new=None, Tensor? v_new=None, "
         "Tensor? cache_slots=None, float k_scale=1.0, float v_scale=1.0, int index_block_m=0, int index_block_n=0) -> ()");
   m.impl("trianglemix_attention", c10::DispatchKey::CUDA, &attention);
+  m.def("trianglemix_decode_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, Tensor block_table, "
+        "Tensor seq_lens, Tensor! partial_o, Tensor! partial_ml, float scale, Tensor? k_new=None, Tensor? v_new=None, "
+        "Tensor? cache_slots=None, float k_scale=1.0, float v_scale=1.0) -> ()");
+  m.impl("trianglemix_decode_attention", c10::DispatchKey::CUDA, &decode_attention);
   m.def("trianglemix_reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, "
         "Tensor slot_mapping) -> ()");
   m.impl("trianglemix_reshape_and_cache", c10::DispatchKey::CUDA, &reshape_and_cache);

@@ -464,6 +464,96 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     return out
 
 
+# --------------------------------------------------------------------------- decode steps with a fixed launch shape
+def decode_workspace(batch: int, num_heads: int, num_kv_heads: int, head_dim: int, device, fp8: bool = False):
+    """Work area of :func:`decode_attention` for a batch size (``tmx_decode_workspace_rows``).  Make it once and keep
+    it: a captured step replays with the same pointers."""
+    with torch.cuda.device(device):
+        rows = int(_lib.load().tmx_decode_workspace_rows(int(batch), int(num_heads), int(num_kv_heads),
+                                                         _lib.TMX_FP8_E4M3 if fp8 else 0, 0))
+    if rows < 0:
+        raise RuntimeError("tmx_decode_workspace_rows failed: " + _lib.load().tmx_last_error().decode("utf-8", "replace"))
+    rows = max(rows, 1)
+    return (torch.empty((rows * head_dim,), dtype=torch.float32, device=device),
+            torch.empty((rows * 2,), dtype=torch.float32, device=device))
+
+
+def decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, block_table: torch.Tensor,
+                     seq_lens: torch.Tensor, scale: float, workspace, k_scale: float = 1.0, v_scale: float = 1.0,
+                     k_new: Optional[torch.Tensor] = None, v_new: Optional[torch.Tensor] = None,
+                     cache_slots: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A step of one-row requests (``tmx_decode_attention``): row ``b`` of ``q`` ``[B, H, D]`` is request ``b``'s
+    query at position ``seq_lens[b] - 1`` and attends to every key of its sequence in the paged cache ``k`` / ``v``
+    (16-bit or fp8).  No index and nothing sized from the requests' lengths: the launch depends on ``B`` only (its
+    pieces are laid out on the device from ``seq_lens``), so the call can be captured in a HIP graph
+    (``torch.cuda.graph``) and replayed after ``seq_lens`` / ``block_table`` / the caches changed in place.
+    ``seq_lens[b] <= 0`` marks a padding row.  ``workspace``: :func:`decode_workspace` for this batch size.
+    ``k_new`` / ``v_new`` / ``cache_slots``: the step's own rows, stored to their slots by the same launch."""
+    if workspace is None or workspace[0] is None or workspace[1] is None:
+        raise RuntimeError("decode_attention needs its work area (ops.decode_workspace for the batch size)")
+    C = _op_binding()
+    if C is not None:
+        # the registered operator: the same library call, argument checks in C++
+        try:
+            C.trianglemix_decode_attention(out, q, k, v, block_table, seq_lens, workspace[0], workspace[1], float(scale),
+                                           k_new, v_new, cache_slots, float(k_scale), float(v_scale))
+        except RuntimeError as e:
+            raise _lib.TmxError(-1, str(e)) from None
+        return out
+    for t, name in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (block_table, "block_table"), (seq_lens, "seq_lens")):
+        _require_gpu(t, name)
+    if q.dim() != 3 or out.shape != q.shape or q.stride(2) != 1 or out.stride(2) != 1:
+        raise RuntimeError("q and out must both be [B, H, D] with a contiguous head dimension")
+    if seq_lens.dtype != torch.int32 or seq_lens.numel() < q.shape[0] or not seq_lens.is_contiguous():
+        raise RuntimeError("seq_lens must be contiguous int32 [B]")
+    if block_table.dtype != torch.int32 or block_table.dim() != 2 or block_table.stride(1) != 1 or block_table.shape[0] < q.shape[0]:
+        raise RuntimeError("block_table must be int32 [B, max_blocks] with contiguous rows")
+    fp8 = k.dtype in (torch.uint8, FP8_DTYPE)
+    if fp8:
+        k, v = _as_bytes(k), _as_bytes(v)
+    elif k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError("q, k, v must share a dtype of bfloat16 or float16 (or K/V be an fp8 cache)")
+    if k.dim() != 4 or k.shape != v.shape or k.stride() != v.stride() or k.stride(-1) != 1 or k.shape[-1] != q.shape[-1]:
+        raise RuntimeError("paged K/V: caches [num_blocks, page_size, Hkv, D] with equal strides")
+    B, H, D = q.shape
+    a = _lib.DecodeArgs()
+    a.struct_size = ctypes.sizeof(_lib.DecodeArgs)
+    a.io_dtype, a.out_dtype, a.scale = dtype_code(q.dtype), dtype_code(out.dtype), float(scale)
+    a.batch, a.num_heads, a.num_kv_heads, a.head_dim = B, H, k.shape[2], D
+    a.out, a.out_stride_t, a.out_stride_h = out.data_ptr(), out.stride(0), out.stride(1)
+    a.q, a.q_stride_t, a.q_stride_h = q.data_ptr(), q.stride(0), q.stride(1)
+    a.k, a.v = k.data_ptr(), v.data_ptr()
+    a.kv_stride_page, a.kv_stride_t, a.kv_stride_h = k.stride(0), k.stride(1), k.stride(2)
+    a.block_table, a.block_table_stride, a.page_size = block_table.data_ptr(), block_table.stride(0), k.shape[1]
+    a.kv_dtype, a.k_scale, a.v_scale = (_lib.TMX_FP8_E4M3, float(k_scale), float(v_scale)) if fp8 else (0, 1.0, 1.0)
+    if (k_new is None) != (v_new is None):
+        raise RuntimeError("k_new and v_new go together")
+    if k_new is not None:
+        _require_gpu(k_new, "k_new")
+        _require_gpu(v_new, "v_new")
+        if (fp8 or k_new.dim() != 3 or k_new.shape != v_new.shape or k_new.stride() != v_new.stride() or k_new.stride(2) != 1
+                or k_new.dtype != q.dtype or v_new.dtype != q.dtype or k_new.shape[0] < B
+                or tuple(k_new.shape[1:]) != (a.num_kv_heads, D)):
+            raise RuntimeError("k_new / v_new must be [B, Hkv, D] rows of the q dtype with equal strides (16-bit cache)")
+        a.k_new, a.v_new, a.new_stride_t, a.new_stride_h = k_new.data_ptr(), v_new.data_ptr(), k_new.stride(0), k_new.stride(1)
+    a.cache_slots = None
+    if cache_slots is not None:
+        _require_gpu(cache_slots, "cache_slots")
+        if k_new is None or cache_slots.dtype != torch.int64 or not cache_slots.is_contiguous() or cache_slots.numel() < B:
+            raise RuntimeError("cache_slots must be contiguous int64 [B] and comes with k_new / v_new")
+        a.cache_slots = cache_slots.data_ptr()
+    a.seq_lens = seq_lens.data_ptr()
+    if workspace is None or workspace[0] is None or workspace[1] is None or workspace[0].dtype != torch.float32:
+        raise RuntimeError("decode_attention needs its work area (ops.decode_workspace for the batch size)")
+    part_o, part_ml = workspace
+    a.partial_o, a.partial_ml = part_o.data_ptr(), part_ml.data_ptr()
+    a.workspace_rows = min(part_o.numel() // D, part_ml.numel() // 2)
+    a.flags = a.reserved = 0
+    with torch.cuda.device(q.device):
+        check(_lib.load().tmx_decode_attention(ctypes.byref(a), _stream(q.device)))
+    return out
+
+
 def eager_attention_f32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, mode: int, si: int = 0,
                         sl: int = 0, last: int = 0, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``softmax(q k^T * scale + mask) v`` in fp32 on contiguous ``[B, N, H, D]`` float32 tensors (the reference's
