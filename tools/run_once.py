@@ -63,12 +63,13 @@ if paged:
 idx = ops.build_block_index(cu, sl, cu_h, sl_h, pat[0], pat[1], pat[2], ops.attention_block_m(H, Hkv), 32,
                             ops.MODES[pat[3]], chunk_tiles=chunk, block_table=bt, page_size=16 if paged else 0)
 work = ops.alloc_workspace(idx, H, D, dev)
+extra_flags = int(os.environ.get("TMX_RUN_FLAGS", "0"))  # e.g. 256 = TMX_ATTN_NO_STRIP, 8 = TMX_ATTN_NO_BAND
 for _ in range(iters):
     if paged:
         ops.attention(q, kc, vc, out, idx, cu, sl, D ** -0.5, block_table=bt, workspace=work,
-                      flags=TMX_ATTN_SKIP_COMBINE)
+                      flags=TMX_ATTN_SKIP_COMBINE | extra_flags)
     else:
         ops.attention(q, k, v, out, idx, cu, sl, D ** -0.5, cu_seqlens_k=cu, workspace=work,
-                      flags=TMX_ATTN_SKIP_COMBINE)
+                      flags=TMX_ATTN_SKIP_COMBINE | extra_flags)
 torch.cuda.synchronize()
 print("done", mode, n, idx.sizes.num_items)
