@@ -173,3 +173,113 @@ def test_plain_import_of_the_extension_registers_the_ops():
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert r.stdout.strip().startswith("[2, ")
+
+
+def test_stand_in_bases_carry_the_concrete_members_of_the_abstract_classes():
+    """abstract.py:27-83 and :114-182: members callers use without the backend defining them."""
+    assert TriangleMixAttentionBackend.full_cls_name() == ("vllm_trianglemix_amd.backend", "TriangleMixAttentionBackend")
+    assert TriangleMixAttentionBackend.supports_quant_query_input is False
+    md = TriangleMixAttentionBackend.make_metadata(
+        num_actual_tokens=1, max_query_len=1, query_start_loc=None, max_seq_len=1, seq_lens=None, block_table=None,
+        slot_mapping=None, query_start_loc_cpu=np.array([0, 1], np.int32), seq_lens_cpu=np.array([1], np.int32), page_size=16)
+    assert isinstance(md, TriangleMixAttentionBackend.get_metadata_cls())
+    impl = TriangleMixAttentionImpl(32, 128, 0.1, 8, None, None, "auto", None, "decoder", None, use_triangle=True)
+    assert impl.can_return_lse_for_decode is False and impl.need_to_return_lse_for_decode is False
+    assert (impl.dcp_world_size, impl.dcp_rank) == (1, 0)
+    assert impl.fused_output_quant_supported(object()) is False
+
+
+def _common_metadata(**extra):
+    return types.SimpleNamespace(
+        num_actual_tokens=4096, max_query_len=4096, max_seq_len=4096,
+        query_start_loc=torch.tensor([0, 4096], dtype=torch.int32), query_start_loc_cpu=torch.tensor([0, 4096], dtype=torch.int32),
+        seq_lens=torch.tensor([4096], dtype=torch.int32), seq_lens_cpu=torch.tensor([4096], dtype=torch.int32),
+        block_table_tensor=torch.zeros((1, 512), dtype=torch.int32), slot_mapping=torch.arange(4096, dtype=torch.int64), **extra)
+
+
+def test_prompt_lengths_from_the_runner_are_optional():
+    """CommonAttentionMetadata has no prompt-length field (utils.py:44-84); a runner that carries one
+    (``prompt_lens_cpu``, filled where gpu_model_runner.py:1189-1205 builds the batch) gets the chunked-prefill
+    semantics of a one-step prefill, one that does not gets per-chunk semantics."""
+    from vllm_trianglemix_amd import ops
+    builder = TriangleMixMetadataBuilder(types.SimpleNamespace(block_size=16), ["l0"], None, torch.device("cpu"))
+    absent = builder.build(0, _common_metadata())
+    assert absent.prompt_lens is None and absent.prompt_lens_cpu is None
+    for carrier in (np.array([8192], np.int64), torch.tensor([8192]), [8192]):
+        present = builder.build(0, _common_metadata(prompt_lens_cpu=carrier))
+        assert present.prompt_lens_cpu.dtype == np.int32 and present.prompt_lens_cpu.tolist() == [8192]
+        assert present.prompt_lens.dtype == torch.int32 and present.prompt_lens.tolist() == [8192]
+    # what the field changes: the first 4096-token chunk of an 8192-token prompt has NO dense trailing rows (they
+    # are the prompt's last 64, in the second chunk); without the field the chunk's own last 64 rows are dense
+    cu, sl = np.array([0, 4096], np.int32), np.array([4096], np.int32)
+    chunk = ops.index_sizes(cu, sl, 4, 32, 64, 32, 32, ops.MODES["triangle"], chunk_tiles=64)
+    whole = ops.index_sizes(cu, sl, 4, 32, 64, 32, 32, ops.MODES["triangle"], chunk_tiles=64,
+                            full_lens_cpu=present.prompt_lens_cpu)
+    assert 0 < whole.nnz_tiles < chunk.nnz_tiles   # fewer attended tiles: no dense tail in this chunk
+
+
+def test_plugin_entry_point_is_declared_and_resolves():
+    """vllm/plugins/__init__.py:11-72 loads ``group='vllm.general_plugins'`` entry points and calls them."""
+    import importlib
+    import os
+    import tomli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "pyproject.toml"), "rb") as f:
+        eps = tomli.load(f)["project"]["entry-points"]["vllm.general_plugins"]
+    (name, target), = eps.items()
+    module, func = target.split(":")
+    assert callable(getattr(importlib.import_module(module), func)) and name == "trianglemix_amd"
+
+
+def test_plugin_wraps_the_attention_layer_constructor():
+    from vllm_trianglemix_amd import plugin
+
+    class Attention(FakeAttention):  # a class of its own: the wrapper replaces __init__ on it
+        pass
+
+    cfg = model_trianglemix_config(TriangleMixInferenceConfig.for_qwen3("8B"))
+    original = plugin.install(Attention, cfg, num_layers=36)
+    wrapped = Attention.__init__
+    assert plugin.install(Attention, cfg) is wrapped and Attention.__init__ is wrapped   # a second call wraps nothing new
+    try:
+        a = Attention(32, 128, 0.1, 8, prefix="model.layers.3.self_attn.attn")
+        assert isinstance(a.impl, TriangleMixAttentionImpl) and a.impl.layer_idx == 3 and a.impl.use_triangle
+        b = Attention(32, 128, 0.1, num_kv_heads=8, prefix="model.layers.30.self_attn.attn")
+        assert isinstance(b.impl, TriangleMixAttentionImpl) and not b.impl.use_triangle
+        # layers outside the path keep the platform's backend
+        for kw in (dict(prefix="vision.blocks.0.attn"), dict(prefix="model.layers.1.attn", use_mla=True),
+                   dict(prefix="model.layers.1.attn", attn_type="encoder_only"),
+                   dict(prefix="model.layers.1.attn", per_layer_sliding_window=4096),
+                   dict(prefix="model.layers.1.attn", sinks=torch.zeros(32)),
+                   dict(prefix="model.layers.1.attn", cache_config=types.SimpleNamespace(cache_dtype="auto", sliding_window=128))):
+            assert Attention(32, 128, 0.1, 8, **kw).default_backend_used, kw
+        assert plugin.layer_index_of("model.layers.17.self_attn.attn") == 17 and plugin.layer_index_of("lm_head") is None
+    finally:
+        Attention.__init__ = original
+
+
+def test_plugin_register_in_a_process_with_and_without_the_switch():
+    """``register`` in a fresh interpreter with a stand-in ``vllm.attention.layer``: the operators are registered
+    either way; the constructor is wrapped only with VLLM_TRIANGLEMIX_ENABLED=1."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, types, torch\n"
+            "class Attention:\n"
+            "    def __init__(self, *a, attn_backend=None, **k): self.b = attn_backend; self.k = k\n"
+            "for n in ('vllm', 'vllm.attention', 'vllm.attention.layer'): sys.modules[n] = types.ModuleType(n)\n"
+            "sys.modules['vllm.attention.layer'].Attention = Attention\n"
+            "from vllm_trianglemix_amd.plugin import register\n"
+            "register(); register()\n"
+            "assert hasattr(torch.ops._trianglemix_C, 'trianglemix_attention')\n"
+            "a = Attention(32, 128, 0.1, 8, prefix='model.layers.0.self_attn.attn')\n"
+            "print(getattr(a.b, '__name__', None), sorted(a.k))\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VLLM_TRIANGLEMIX")}
+    off = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert off.returncode == 0, off.stderr
+    assert off.stdout.split()[0] == "None"
+    on = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300,
+                        env={**env, "VLLM_TRIANGLEMIX_ENABLED": "1", "VLLM_TRIANGLEMIX_LAYERS": "8", "VLLM_TRIANGLEMIX_NUM_LAYERS": "36"})
+    assert on.returncode == 0, on.stderr
+    assert on.stdout.startswith("TriangleMixAttentionBackend ['layer_idx', 'prefix', 'trianglemix_config']"), on.stdout

@@ -35,11 +35,34 @@ try:  # pragma: no cover - depends on the host installation
     from vllm.attention.backends.abstract import AttentionType as _AttentionType
     _DECODER = _AttentionType.DECODER
 except Exception:  # vLLM (or one of its dependencies) is not installed
-    class _BackendBase:  # the members vllm/attention/backends/abstract.py:27-83 declares
+    class _BackendBase:
+        """Stand-in with the concrete members of ``AttentionBackend`` (vllm/attention/backends/abstract.py:27-83);
+        the abstract ones are defined by the subclass below."""
         accept_output_buffer: bool = False
+        supports_quant_query_input: bool = False
+
+        @classmethod
+        def make_metadata(cls, *args, **kwargs):
+            return cls.get_metadata_cls()(*args, **kwargs)
+
+        @staticmethod
+        def get_kv_cache_stride_order() -> Tuple[int, ...]:
+            raise NotImplementedError
+
+        @classmethod
+        def full_cls_name(cls) -> Tuple[str, str]:
+            return (cls.__module__, cls.__qualname__)
 
     class _ImplBase:
-        pass
+        """Stand-in with the concrete members of ``AttentionImpl`` (abstract.py:114-182): no decode context
+        parallelism outside a vLLM process, so the group size is 1."""
+        can_return_lse_for_decode: bool = False
+        need_to_return_lse_for_decode: bool = False
+        dcp_world_size: int = 1
+        dcp_rank: int = 0
+
+        def fused_output_quant_supported(self, quant_key) -> bool:
+            return False
 
     _DECODER = "decoder"  # vllm/attention/backends/abstract.py:17-24
 
