@@ -67,6 +67,9 @@ def parse():
                          "milliseconds of load before its clocks settle (0.25 ms steps: 10 warm-up steps are 2.5 ms)")
     ap.add_argument("--model", choices=sorted(MODELS), default="8b", help="head shape and K/V cache type")
     ap.add_argument("--seq-len", type=int, default=0, help="prompt length (0: the model's configuration)")
+    ap.add_argument("--index-in-launch", action="store_true",
+                    help="the attention call builds the step's index itself, inside its launch where it can "
+                         "(default: a build launch ahead of the attention)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks rendezvous over gloo, size their shard of the job on the host and print "
                          "the line without a measurement (checks the launcher and the sharding arithmetic)")
@@ -355,7 +358,7 @@ def main():
     out = torch.empty_like(inp["q"])
     kc, vc = inp["kv_cache"][0], inp["kv_cache"][1]
 
-    def build(mode, pages=True):
+    def build(mode, pages=True, defer=False):
         # pages of every listed tile are resolved by the builder (block table lookups leave the attention loop);
         # the piece length is the library's advice for this batch (one piece of the dense rows per CU: 64 tiles here)
         if mode == "triangle" and args.chunk_tiles > 0:
@@ -365,10 +368,10 @@ def main():
                                             ops.units_per_item(H, Hkv))
         if not pages:
             return ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn,
-                                         ops.MODES[mode], chunk_tiles=chunk)
+                                         ops.MODES[mode], chunk_tiles=chunk, defer=defer)
         return ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn,
                                      ops.MODES[mode], chunk_tiles=chunk, block_table=inp["block_table"],
-                                     page_size=PAGE)
+                                     page_size=PAGE, defer=defer)
 
     idx0 = build("triangle")
     work = ops.alloc_workspace(idx0, H, D, dev)
@@ -378,8 +381,13 @@ def main():
         ops.attention(inp["q"], kc, vc, out, idx, inp["cu"], inp["sl"], scale, block_table=inp["block_table"],
                       workspace=work, flags=flags | base_flags)
 
+    # One step = the index of the step built from the batch description + the attention over it: a build launch,
+    # then the attention.  --index-in-launch: the attention call builds the index itself (TMX_ATTN_BUILD_INDEX;
+    # workgroup 0 of the launch builds it while the band workgroups, which do not read it, already stream) -- the
+    # same index and output; measured no faster at 32k tokens and slower at 8k (the work-list workgroups, which
+    # have to wait for it, are on the launch's critical path), so it is not the default.
     def step():
-        attend(build("triangle"))
+        attend(build("triangle", defer=args.index_in_launch))
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -487,7 +495,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "kernel_ms": t_attn_ms, "combine_ms": t_comb_ms, "index_build_ms": t_index_ms}
+                "kernel_ms": t_attn_ms, "combine_ms": t_comb_ms, "index_build_ms": t_index_ms,
+                "index_build": "by the attention call (inside its launch where the step allows)" if args.index_in_launch
+                               else "a launch of its own"}
 
     if not args.no_baselines and rank == 0 and not fp8:
         # dense-causal baselines at the same shape (attention-op level)

@@ -302,6 +302,20 @@ typedef struct tmx_attention_args_t {
 /* Measurement aid: the decode kernel forms its weighted sum on the vector units instead of the matrix cores
  * (its first implementation; same results within the tolerance of the attention). */
 #define TMX_ATTN_DECODE_VALU 128u
+/* The index has NOT been built yet: this call builds it (args->index describes the buffers exactly as for
+ * tmx_build_block_index, from args->cu_seqlens_q / seq_lens) and attends with it.  Replaces the pair
+ * "mask generator, then attention" of the reference (vllm/attention/trianglemix_attention.py:310-340 ahead of
+ * vllm/attention/ascend_trianglemix.py:88-106) by ONE call: where the launch has workgroups that do not read the
+ * index (the band workgroups of a long triangle prompt), no other kernel of the call needs it first, the batch has
+ * at most 16 requests and the index fits one workgroup's build (up to 1024 q-blocks, head size 128, 16-bit K/V),
+ * workgroup 0 of the attention launch builds it while those workgroups already stream, and the workgroups that
+ * walk the work list start when it is complete; every other step gets the build as a launch of its own ahead of
+ * the attention.  (Measured on MI355X the in-launch form saves the build launch and gives the time back at the
+ * end of the attention launch: no faster at 32k tokens, slower at 8k; callers after speed build first.)
+ * Same index and same results as the two calls; the counts in args (num_items,
+ * num_partials, num_split_qblocks, nnz_tiles) come from tmx_index_sizes as always.  Afterwards the index is
+ * built: later calls of the step (the other layers) pass it without the flag. */
+#define TMX_ATTN_BUILD_INDEX 256u
 
 int tmx_attention(const tmx_attention_args_t* args, void* stream);
 

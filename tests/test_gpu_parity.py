@@ -1241,6 +1241,99 @@ def test_resolved_pages_are_used_only_with_the_block_table_they_came_from(monkey
         assert_close(out.cpu().numpy(), ref, f"index with resolved pages, {binding} binding", info=name)
 
 
+@pytest.mark.parametrize("binding", ["torch", "ctypes"])
+@pytest.mark.parametrize("case", [
+    # (q_lens, seq_lens, H, Hkv, dtype, paged, mode, chunk): one long prompt, the benchmark's shapes in small
+    dict(q_lens=[8192], seq_lens=[8192], H=8, Hkv=2, dtype=torch.bfloat16, paged=True, mode="triangle", chunk=16),
+    dict(q_lens=[32768], seq_lens=[32768], H=8, Hkv=2, dtype=torch.bfloat16, paged=True, mode="triangle", chunk=64),
+    # a ragged batch below 1024 q-blocks, contiguous K/V, fp16, 8 : 1 heads (two head chunks per K/V head)
+    dict(q_lens=[3000, 5000, 2049], seq_lens=[3000, 5000, 2049], H=8, Hkv=1, dtype=torch.float16, paged=False,
+         mode="triangle", chunk=8),
+    # chunked prefill: context in the cache, prompt lengths known
+    dict(q_lens=[4096], seq_lens=[12288], H=8, Hkv=2, dtype=torch.bfloat16, paged=True, mode="triangle", chunk=16,
+         full=[16384]),
+    # steps whose build cannot ride in the attention launch get it as a launch of their own: a causal layer (dense
+    # kernel first), decode rows beside a prompt (decode kernel first), more than 1024 q-blocks, head size 64
+    dict(q_lens=[4096], seq_lens=[4096], H=8, Hkv=2, dtype=torch.bfloat16, paged=True, mode="causal", chunk=16),
+    dict(q_lens=[4096, 1, 1], seq_lens=[4096, 700, 3000], H=8, Hkv=2, dtype=torch.bfloat16, paged=True, mode="triangle", chunk=16),
+    dict(q_lens=[36000], seq_lens=[36000], H=4, Hkv=1, dtype=torch.bfloat16, paged=True, mode="triangle", chunk=64),
+    dict(q_lens=[4096], seq_lens=[4096], H=8, Hkv=2, D=64, dtype=torch.bfloat16, paged=False, mode="triangle", chunk=16),
+], ids=lambda c: f"{c['mode']}-{'+'.join(map(str, c['q_lens']))}-{c['H']}x{c['Hkv']}-{str(c['dtype'])[6:]}")
+def test_index_built_by_the_attention_call(monkeypatch, binding, case):
+    """``build_block_index(defer=True)`` + ``attention``: the call builds the index itself (TMX_ATTN_BUILD_INDEX),
+    inside the attention launch where that launch has band workgroups to run meanwhile.  Every array of the index
+    and the output must be bit-identical to the two-call form, repeatedly (the buffers of one round are the next
+    round's: what an earlier build left in them must not read as "built"), and a later call reuses the index."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "_BINDING", binding)
+    H, Hkv, D, page = case["H"], case["Hkv"], case.get("D", 128), 16
+    q_lens, seq_lens, dtype, paged = case["q_lens"], case["seq_lens"], case["dtype"], case["paged"]
+    B, T = len(q_lens), sum(q_lens)
+    g = torch.Generator().manual_seed(4242)
+    q = torch.randn((T, H, D), generator=g).to(DEV).to(dtype)
+    cu_h = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    sl_h = np.asarray(seq_lens, np.int32)
+    cu, sld = torch.from_numpy(cu_h).to(DEV), torch.from_numpy(sl_h).to(DEV)
+    kw = {}
+    if paged:
+        nblk = sum((s + page - 1) // page for s in seq_lens)
+        kc = torch.randn((nblk, page, Hkv, D), generator=g).to(DEV).to(dtype)
+        vc = torch.randn((nblk, page, Hkv, D), generator=g).to(DEV).to(dtype)
+        perm = torch.randperm(nblk, generator=g).to(torch.int32)
+        width = max((s + page - 1) // page for s in seq_lens)
+        bt = torch.zeros((B, width), dtype=torch.int32)
+        nxt = 0
+        for b, sq in enumerate(seq_lens):
+            nb = (sq + page - 1) // page
+            bt[b, :nb] = perm[nxt:nxt + nb]
+            nxt += nb
+        bt = bt.to(DEV)
+        kw = dict(block_table=bt)
+        build_kw = dict(block_table=bt, page_size=page)
+    else:
+        kc = torch.randn((sum(seq_lens), Hkv, D), generator=g).to(DEV).to(dtype)
+        vc = torch.randn((sum(seq_lens), Hkv, D), generator=g).to(DEV).to(dtype)
+        cu_k = torch.from_numpy(np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)).to(DEV)
+        kw = dict(cu_seqlens_k=cu_k)
+        build_kw = {}
+    if "full" in case:
+        fl_h = np.asarray(case["full"], np.int32)
+        build_kw.update(full_lens=torch.from_numpy(fl_h).to(DEV), full_lens_cpu=fl_h)
+    bm = ops.attention_block_m(H, Hkv)
+    mode = ops.MODES[case["mode"]]
+
+    def make(defer):
+        return ops.build_block_index(cu, sld, cu_h, sl_h, 4, 32, 64, bm, 32, mode, chunk_tiles=case["chunk"], tri_min_len=2048,
+                                     defer=defer, **build_kw)
+
+    ref_idx = make(False)
+    ref_out = torch.full((T, H, D), float("nan"), dtype=dtype, device=DEV)
+    ops.attention(q, kc, vc, ref_out, ref_idx, cu, sld, D ** -0.5, **kw)
+    names = ["row_ptr", "col_idx", "qb_meta", "part_ptr", "items", "split_qb", "totals"] + (["tile_pages"] if paged else [])
+    for rnd in range(3):
+        idx = make(True)
+        assert not idx.built
+        out = torch.full((T, H, D), float("nan"), dtype=dtype, device=DEV)
+        ops.attention(q, kc, vc, out, idx, cu, sld, D ** -0.5, **kw)
+        assert idx.built
+        torch.cuda.synchronize()
+        for name in names:
+            assert torch.equal(getattr(idx, name), getattr(ref_idx, name)), (name, rnd)
+        assert torch.equal(out.view(torch.int16), ref_out.view(torch.int16)), rnd
+        # the built index serves the step's other layers like any other
+        out2 = torch.full((T, H, D), float("nan"), dtype=dtype, device=DEV)
+        ops.attention(q, kc, vc, out2, idx, cu, sld, D ** -0.5, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out2.view(torch.int16), ref_out.view(torch.int16)), rnd
+        del idx  # (its buffer goes back to the allocator: the next round's index lands on it)
+    # the batch description of the building call must be the one the index was sized for
+    idx = make(True)
+    with pytest.raises(RuntimeError, match="deferred index"):
+        ops.attention(q, kc, vc, out, idx, cu.clone(), sld, D ** -0.5, **kw)
+    idx.build_now()
+    assert idx.built and torch.equal(idx.items, ref_idx.items)
+
+
 def test_backend_length_gate_2048_vs_2049(golden_attention):
     """The reference gives no mask up to 2048 tokens and the triangle mask from 2049 on
     (trianglemix_attention.py:330-332).  Through the backend: a 2048-token prompt runs plain causal attention,

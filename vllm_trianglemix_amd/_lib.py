@@ -93,6 +93,7 @@ class DecodeArgs(Structure):
 
 TMX_ATTN_SKIP_COMBINE, TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES, TMX_ATTN_NO_BAND, TMX_ATTN_NO_DENSE = 1, 2, 4, 8, 16
 TMX_ATTN_NO_DECODE, TMX_ATTN_DECODE_ONLY, TMX_ATTN_DECODE_VALU = 32, 64, 128
+TMX_ATTN_BUILD_INDEX = 256  # the index is still to be built: this call builds it (inside the attention launch where it can)
 
 
 _lib = None

@@ -241,6 +241,44 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.exp_mode = 0;
   p.xcd_generic = p.xcd_band = 0;
   hipStream_t s = (hipStream_t)stream;
+  // query heads per decode workgroup (all of them share the K/V loads), its units per item, and whether the step
+  // has a decode launch (below)
+  const int hw_d = G % 8 == 0 ? 8 : 4;
+  const int Yd = a->num_kv_heads * (G / hw_d > 0 ? G / hw_d : 1);
+  const bool pure = a->total_q == a->batch;
+  const bool decode_will_run = !has_bias && G % 4 == 0 && a->head_dim == 128 && (!paged || a->page_size >= 16) &&
+                               (a->mode != TMX_MODE_TRIANGLE || a->last >= 2) &&
+                               !(a->flags & (TMX_ATTN_NO_DECODE | TMX_ATTN_ONLY_COMBINE)) &&
+                               (pure || (a->batch >= 2 && (long long)a->num_items * Yd <= kDecodeMaxMixedGrid));
+  // The index is still to be built (TMX_ATTN_BUILD_INDEX).  Inside the attention launch when that launch has band
+  // workgroups to run meanwhile, nothing ahead of it reads the index (no dense causal or decode launch in this
+  // call) and one workgroup can build it; else as a launch of its own, first.
+  p.ix_build = 0;
+  p.ix_flag = nullptr;
+  p.ix_epoch = 0;
+  p.ix = IndexParams{};
+  if (a->flags & TMX_ATTN_BUILD_INDEX) {
+    // (batches of a few requests: the band workgroups, which cannot read the index yet, walk the batch description
+    // to place a q-block)
+    const bool in_launch = p.band_on && !p.dense_on && !decode_will_run && ix->cap_qblocks <= 1024 && p.units_total > 0 &&
+                           a->batch <= 16 &&
+                           attention_kernel_builds_index(a->head_dim, has_bias, fp8) &&
+                           !(a->flags & (TMX_ATTN_ONLY_COMBINE | TMX_ATTN_SHORT_QUERIES));
+    if (in_launch) {
+      const int rc = index_params_from(ix, a->cu_seqlens_q, a->seq_lens, &p.ix);
+      if (rc != TMX_OK) return rc;
+      // the epoch goes to an 8-byte slot of the build's work area that the single-workgroup build leaves alone (the
+      // per-block totals of the blocked form: at least 8 ints); epochs never repeat within a process and carry a
+      // tag in their upper half, so that no earlier content of the buffer reads as "built"
+      static std::atomic<unsigned long long> epoch_counter{0};
+      p.ix_flag = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(p.ix.blk_tot) + 7) & ~(uintptr_t)7);
+      p.ix_epoch = (0x544D5849ull << 32) | (epoch_counter.fetch_add(1, std::memory_order_relaxed) + 1);
+      p.ix_build = 1;
+    } else {
+      const int rc = tmx_build_block_index(const_cast<tmx_index_t*>(ix), a->cu_seqlens_q, a->seq_lens, nullptr, nullptr, stream);
+      if (rc != TMX_OK) return rc;
+    }
+  }
   if (p.dense_on) {
     DenseParams d;
     d.q = a->q;
@@ -288,13 +326,7 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   p.decode_on = 0;
   uint32_t flags = a->flags;
   {
-    const int hw_d = G % 8 == 0 ? 8 : 4;  // query heads per decode workgroup (all of them share the K/V loads)
-    const int Yd = a->num_kv_heads * (G / hw_d > 0 ? G / hw_d : 1);
-    const bool shape_ok = !has_bias && G % 4 == 0 && a->head_dim == 128 && (!paged || a->page_size >= 16) &&
-                          (a->mode != TMX_MODE_TRIANGLE || a->last >= 2) &&
-                          !(a->flags & (TMX_ATTN_NO_DECODE | TMX_ATTN_ONLY_COMBINE));
-    const bool pure = a->total_q == a->batch;
-    if (shape_ok && (pure || (a->batch >= 2 && (long long)a->num_items * Yd <= kDecodeMaxMixedGrid))) p.decode_on = 1;
+    if (decode_will_run) p.decode_on = 1;
     if (p.decode_on) {
       DecodeParams d;
       d.q = a->q;

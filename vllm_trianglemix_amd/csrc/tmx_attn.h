@@ -4,6 +4,7 @@
 #pragma once
 #include "tmx_common.h"
 #include "tmx_attn_switches.h"
+#include "tmx_index_scan.h"  // the index build as the first thing workgroup 0 does (TMX_ATTN_BUILD_INDEX)
 #include "tmx_dense.h"   // kDenseMinRows: which requests the dense causal kernel takes
 #include "tmx_decode.h"  // decode_row: which rows the decode kernel takes
 
@@ -152,6 +153,13 @@ struct AttnParams {
   int bias_rows, bias_cols, bias_dtype, out_dtype;
   float scale_log2;
   float k_scale, v_scale;     // fp8 K/V cache: value = fp8 x scale
+  // In-launch index build (ix_build): workgroup 0 builds the index from `ix`, then stores ix_epoch to *ix_flag
+  // (device scope, release); the other work-list workgroups wait for that value before they read anything of the
+  // index.  The band workgroups never read it.
+  int ix_build;
+  unsigned long long* ix_flag;
+  unsigned long long ix_epoch;
+  IndexParams ix;
 };
 
 // Read through the scalar (constant) path: the index, the block table and the
@@ -354,6 +362,8 @@ constexpr int kMaxDevices = 64;  // per-device host caches (resident workgroups,
 // ---- host side: one launcher per kernel file ----
 // Work-list + band workgroups (tmx_attn_kernel.hip).  bf16: the 16-bit type of q / k / v (else fp16).
 int launch_attention_kernel(const AttnParams& p, bool bf16, int head_dim, bool paged, bool has_bias, bool fp8, hipStream_t s);
+// Whether launch_attention_kernel has the form that builds the index in the launch for this shape (p.ix_build).
+bool attention_kernel_builds_index(int head_dim, bool has_bias, bool fp8);
 // Merge pass over the pieces of the split q-blocks (tmx_attn_combine.hip).
 int launch_combine_kernel(const AttnParams& p, bool bf16, int head_dim, int64_t num_split, hipStream_t s);
 

@@ -19,7 +19,10 @@ namespace tmx {
 // V conversion of bf16 launches, expands them there into the 16-bit image the arithmetic reads: value x scale
 // rounded once to the 16-bit type of q (the descale of the reference's attention kernels,
 // vllm/v1/attention/backends/rocm_attn.py:421-422); V of a bf16 launch goes on from that bf16 value to fp16 (exact).
-template <typename TR, int D, bool PAGED, bool FP8 = false>
+// BUILD: the index is being built by workgroup 0 of this launch meanwhile: nothing of it is read here -- the
+// request and the first row of a q-block (qb_meta in the index) are derived from the batch description instead,
+// request by request (the launch takes this form for batches of a few requests only).
+template <typename TR, int D, bool PAGED, bool FP8 = false, bool BUILD = false>
 __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned lds_base, const int kvc, int qb, const int qb_end,
                                           const bool own_stamps) {
   constexpr int KS = D / 32, DB = D / 16, ROWB = D * 2, CPR = D / 8;
@@ -114,7 +117,21 @@ __device__ __forceinline__ void band_body(const AttnParams& p, const unsigned ld
 #pragma unroll 1
   while (qb < qb_end) {
     // ---- next segment: consecutive band q-blocks of one request inside [qb, qb_end) ----
-    const int b = sload(p.qb_meta + 2 * qb), row0 = sload(p.qb_meta + 2 * qb + 1);
+    int b, row0;
+    if constexpr (BUILD) {
+      int before = 0;  // q-blocks of the requests ahead of b (32 rows each on this path)
+      b = 0;
+      for (;;) {
+        const int nqb = (sload(p.cu_q + b + 1) - sload(p.cu_q + b) + 31) >> 5;
+        if (qb < before + nqb || b >= p.batch - 1) break;
+        before += nqb;
+        ++b;
+      }
+      row0 = (qb - before) * 32;
+    } else {
+      b = sload(p.qb_meta + 2 * qb);
+      row0 = sload(p.qb_meta + 2 * qb + 1);
+    }
     const int q_start = sload(p.cu_q + b);
     const int q_len = sload(p.cu_q + b + 1) - q_start;
     const int n = sload(p.seq_lens + b);

@@ -46,7 +46,10 @@ namespace tmx {
 // the step, one 1-KiB piece each, into the 16-bit image the arithmetic reads (value x scale, rounded once to
 // the 16-bit type: the descale of the reference's attention kernels, vllm/v1/attention/backends/rocm_attn.py:421-422),
 // with a second barrier between the conversion and the arithmetic.
-template <typename TR, int D, int NS, bool PAGED, bool HAS_BIAS, bool FP8>
+// BUILD: the launch also builds the index (TMX_ATTN_BUILD_INDEX).  Workgroup 0 -- dispatched first, and the whole
+// grid is resident, so nobody it waits for and nobody waiting for it can be left out -- runs the single-workgroup
+// build before its own work and publishes an epoch; the other work-list workgroups sleep until they read that epoch.
+template <typename TR, int D, int NS, bool PAGED, bool HAS_BIAS, bool FP8, bool BUILD = false>
 __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p) {
   constexpr int KS = D / 32;            // k-steps of S^T = K Q^T
   constexpr int DB = D / 16;            // 16-column output blocks
@@ -80,6 +83,42 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 
   __shared__ __attribute__((aligned(1024))) char lds[NS * ENTRY + IMG + kWaves * QREG];
 
+  if constexpr (BUILD) {
+    // (ahead of everything else: nothing computed for the attention is live across the build)
+    static_assert(sizeof(IndexScanShared) <= sizeof(lds), "the build's LDS must fit the attention's");
+    if (blockIdx.x == 0) {
+      index_scan_body<64 * kWaves>(p.ix, *reinterpret_cast<IndexScanShared*>(lds));
+      // The barrier waits for every wave's stores to have reached this XCD's L2; ONE thread then writes that L2
+      // back (the release of its device-scope store) and publishes the epoch.  (A device-scope fence per thread
+      // would write back and invalidate the whole L2 over and over under the band workgroups' feet.)
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(p.ix_flag, p.ix_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else if ((int)blockIdx.x < p.n_generic) {
+      // (a bounded wait, about two seconds: a workgroup that never sees the epoch leaves without touching anything
+      // rather than keeping the GPU; the build takes ten to twenty microseconds)
+      int* const seen = reinterpret_cast<int*>(lds);
+      if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+          if (__hip_atomic_load(p.ix_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.ix_epoch) {
+            ok = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(16);
+        }
+        *seen = ok;
+      }
+      __syncthreads();
+      const int ok = *seen;
+      __syncthreads();  // (the LDS word is free again)
+      if (!ok) return;
+      // No cache invalidation on this side: nothing of the index has been read by this launch before the epoch is
+      // seen (the band workgroups never read it), and a launch starts with the caches clean of other launches'
+      // lines -- so no cache on this workgroup's path can hold an older copy of what workgroup 0 wrote.
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,14 +139,13 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
 #endif
       const UnitLane bl = unit_of(bid - ngrid, p.Y, p.Hkv, p.G / p.Gw, p.xcd_band);
       const int qb0 = bl.lane * p.band_rl;
-      band_body<TR, D, PAGED, FP8>(p, lds_base, bl.kvc, qb0, imin(p.band_tail0, qb0 + p.band_rl), true);
+      band_body<TR, D, PAGED, FP8, BUILD>(p, lds_base, bl.kvc, qb0, imin(p.band_tail0, qb0 + p.band_rl), true);
       return;
     }
   }
 #ifdef TMX_TUNING
   if (p.exp_mode & 1) return;
 #endif
-
   const int sub = wave & 3, half = wave >> 2;
   const int hg = sub & (p.Gw - 1);                  // this wave's head inside the workgroup's head group
   const int rb16 = (sub >> p.gw_shift) * 2 + half;   // its 16-row block inside the q-block
@@ -975,9 +1013,9 @@ static int persistent_grid(long long resident, const AttnParams& p, unsigned* gr
 
 constexpr int kRingSlotsFp8 = 4;  // fp8 K/V: entries of half the size, one more of them
 
-template <typename TR, int D, bool PAGED, bool HAS_BIAS, bool FP8 = false>
+template <typename TR, int D, bool PAGED, bool HAS_BIAS, bool FP8 = false, bool BUILD = false>
 static int launch_attn(const AttnParams& p_in, hipStream_t s) {
-  auto kernel = attn_kernel<TR, D, FP8 ? kRingSlotsFp8 : kRingSlots, PAGED, HAS_BIAS, FP8>;
+  auto kernel = attn_kernel<TR, D, FP8 ? kRingSlotsFp8 : kRingSlots, PAGED, HAS_BIAS, FP8, BUILD>;
   static std::atomic<unsigned> resident_cache[kMaxDevices];  // per device: resident workgroups of this instantiation (0: not asked yet)
   long long resident = 0;
   int cus = 0;
@@ -1057,6 +1095,15 @@ static int launch_attn(const AttnParams& p_in, hipStream_t s) {
 
 template <typename TR, int D>
 static int launch_for(const AttnParams& p, bool paged, bool has_bias, bool fp8, hipStream_t s) {
+  if (p.ix_build) {
+    // (the entry point asks attention_kernel_builds_index first)
+    if constexpr (D == 128) {
+      if (has_bias || fp8) return TMX_ERR_UNSUPPORTED;
+      return paged ? launch_attn<TR, 128, true, false, false, true>(p, s) : launch_attn<TR, 128, false, false, false, true>(p, s);
+    } else {
+      return TMX_ERR_UNSUPPORTED;
+    }
+  }
   if (fp8) {
     if constexpr (D == 128) return launch_attn<TR, 128, true, false, true>(p, s);
     else return TMX_ERR_UNSUPPORTED;
@@ -1064,6 +1111,8 @@ static int launch_for(const AttnParams& p, bool paged, bool has_bias, bool fp8, 
   if (paged) return has_bias ? launch_attn<TR, D, true, true>(p, s) : launch_attn<TR, D, true, false>(p, s);
   return has_bias ? launch_attn<TR, D, false, true>(p, s) : launch_attn<TR, D, false, false>(p, s);
 }
+
+bool attention_kernel_builds_index(int head_dim, bool has_bias, bool fp8) { return head_dim == 128 && !has_bias && !fp8; }
 
 int launch_attention_kernel(const AttnParams& p, bool bf16, int head_dim, bool paged, bool has_bias, bool fp8, hipStream_t s) {
   if (bf16) return head_dim == 64 ? launch_for<Bf16Traits, 64>(p, paged, has_bias, fp8, s) : launch_for<Bf16Traits, 128>(p, paged, has_bias, fp8, s);

@@ -154,7 +154,8 @@ class BlockIndex:
     arrays are slices of ``buf`` (16-byte aligned starts), made on demand, so a step pays for one
     allocation and one launch sequence."""
     __slots__ = ("buf", "_off", "sizes", "c", "batch", "block_m", "block_n", "mode", "si", "sl", "last",
-                 "chunk_tiles", "tri_min_len", "block_table", "full_lens", "full_lens_cpu", "_op_args")
+                 "chunk_tiles", "tri_min_len", "block_table", "full_lens", "full_lens_cpu", "_op_args", "built",
+                 "_batch_tensors")
 
     def __init__(self, buf, off, sizes, c, batch, block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
                  block_table, full_lens, full_lens_cpu):
@@ -164,6 +165,19 @@ class BlockIndex:
         # kept alive: the C struct points at them
         self.block_table, self.full_lens, self.full_lens_cpu = block_table, full_lens, full_lens_cpu
         self._op_args = None
+        # False: the buffers are allocated and described, nothing is in them yet (build_block_index(defer=True));
+        # the first attention call with the index builds it (TMX_ATTN_BUILD_INDEX), or build_now()
+        self.built = True
+        self._batch_tensors = None
+
+    def build_now(self) -> None:
+        """Builds a deferred index with a launch of its own (what the first attention call would otherwise do)."""
+        if self.built:
+            return
+        cu, sl = self._batch_tensors
+        with torch.cuda.device(cu.device):
+            check(_lib.load().tmx_build_block_index(ctypes.byref(self.c), _ptr(cu), _ptr(sl), None, None, _stream(cu.device)))
+        self.built = True
 
     def op_args(self):
         """(the eight index arrays as the list ``torch.ops._trianglemix_C`` takes, tile_pages or None, the
@@ -217,9 +231,12 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
                       si: int, sl: int, last: int, block_m: int, block_n: int, mode: int,
                       chunk_tiles: int = DEFAULT_CHUNK_TILES, tri_min_len: int = 0,
                       block_table: Optional[torch.Tensor] = None, page_size: int = 0,
-                      full_lens: Optional[torch.Tensor] = None, full_lens_cpu=None) -> BlockIndex:
+                      full_lens: Optional[torch.Tensor] = None, full_lens_cpu=None, defer: bool = False) -> BlockIndex:
     """Build the packed block-sparse index on the device (one allocation, at most two launches, no
-    host synchronisation; buffer sizes come from the host copies).  With a
+    host synchronisation; buffer sizes come from the host copies).  ``defer``: only size, allocate and describe
+    the index; the first ``attention`` call that gets it builds it as part of its own work
+    (``TMX_ATTN_BUILD_INDEX``: inside the attention launch where that launch has workgroups that do not need the
+    index, else as a launch of its own first) -- same index, same results.  With a
     ``block_table`` (int32 ``[B, max_blocks]``) and ``page_size`` the physical
     pages of every listed tile are resolved as well (paged K/V, ``block_n`` 32).
     ``full_lens`` (int32 ``[B]`` on the device, with its host copy): the length each
@@ -279,12 +296,17 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
         c.tile_pages, c.pages_block_table, c.pages_block_table_stride, c.pages_page_size = None, None, 0, 0
     c.full_lens = None if full_lens is None else full_lens.data_ptr()
     c.full_lens_host = None if fl_h is None else _np_ptr(fl_h)
+    idx = BlockIndex(buf, off, sz, c, batch, block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
+                     block_table, full_lens, fl_h)
+    if defer:
+        idx.built = False
+        idx._batch_tensors = (cu_seqlens_q, seq_lens)
+        return idx
     with torch.cuda.device(dev):
         check(_lib.load().tmx_build_block_index(ctypes.byref(c), _ptr(cu_seqlens_q), _ptr(seq_lens),
                                                 _np_ptr(cu_h),
                                                 _np_ptr(sl_h), _stream(dev)))
-    return BlockIndex(buf, off, sz, c, batch, block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
-                      block_table, full_lens, fl_h)
+    return idx
 
 
 # --------------------------------------------------------------------------- attention
@@ -307,6 +329,15 @@ def _op_binding():
             _BINDING = "ctypes"  # the operator library is not built: the ctypes binding serves
             return None
     return _op_ns
+
+
+def _check_batch_of(index: BlockIndex, cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor) -> None:
+    """A deferred index is built from the batch description of the attention call that builds it: it must be the one
+    the index was sized for."""
+    cu, sl = index._batch_tensors
+    if cu.data_ptr() != cu_seqlens_q.data_ptr() or sl.data_ptr() != seq_lens.data_ptr():
+        raise RuntimeError("a deferred index is built by the first attention call: pass the cu_seqlens_q / seq_lens "
+                           "tensors it was sized with (or call index.build_now() first)")
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, index: BlockIndex,
@@ -351,6 +382,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
         # used with another table falls back to the kernel's own block-table lookups, as the ctypes route does)
         if tile_pages is not None and not index.pages_resolved_from(block_table, k.shape[1] if k.dim() == 4 else 0):
             tile_pages = None
+            index.build_now()  # (a deferred index is built with the table its pages belong to, not with this call's)
+        if not index.built:
+            _check_batch_of(index, cu_seqlens_q, seq_lens)
+            flags = int(flags) | _lib.TMX_ATTN_BUILD_INDEX
         try:
             C.trianglemix_attention(out, q, k, v, block_table, cu_seqlens_q, seq_lens, cu_seqlens_k, index_list,
                                     tile_pages, part_o, part_ml, bias, float(scale),
@@ -359,7 +394,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
                                     float(k_scale), float(v_scale), index.block_m, index.block_n)
         except RuntimeError as e:
             raise _lib.TmxError(-1, str(e)) from None
+        index.built = True
         return out
+    if not index.built:
+        _check_batch_of(index, cu_seqlens_q, seq_lens)
+        flags = int(flags) | _lib.TMX_ATTN_BUILD_INDEX
     for t, name in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (cu_seqlens_q, "cu_seqlens_q"),
                     (seq_lens, "seq_lens")):
         _require_gpu(t, name)
@@ -461,6 +500,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
         lib = _lib.load()
         entry = lib.tmx_attention_static_ws if static_workspace else lib.tmx_attention
         check(entry(ctypes.byref(a), _stream(q.device)))
+    index.built = True
     return out
 
 
