@@ -420,40 +420,9 @@ def main():
     tokens_per_step = batch * n  # whole job: every prompt is processed once per step (heads are split over ranks)
     value = tokens_per_step / (elapsed / args.steps)
 
-    # ---- the layer's only exchange step: row-parallel o_proj GEMM + all-reduce of its partial products over the
-    # ranks (linear.py:1358-1359; RCCL over xGMI), chunked over tokens so that a chunk's all-reduce runs beside the
-    # next chunk's GEMM.  Always timed when there is more than one rank (every rank takes part), reported beside
-    # the attention-only `value`, never inside it.
     extra = {}
-    if world > 1 or args.oproj:
-        hidden = cfg["hidden"]
-        w = (torch.randn((hidden, H * D), device=dev) * 0.02).bfloat16()
-        chunk_tokens = 8192
-        proj = RowParallelOutputProjection(w, chunk_tokens=chunk_tokens if world > 1 else 0)
-        for _ in range(2):
-            y = proj(out)
-        sync_all()
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            y = proj(out)
-        sync_all()
-        t_op = (time.perf_counter() - t0) / reps
-        if world > 1:
-            import torch.distributed as dist
-            tt = torch.tensor([t_op], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_op = float(tt.item())
-        extra["oproj_gemm_allreduce_ms"] = t_op * 1e3
-        # (serial sum: the attention of a layer is followed by its projection; no overlap between the two is assumed)
-        extra["layer_ms_with_oproj"] = ms_per_step + t_op * 1e3
-        extra["oproj"] = {"tokens": int(out.shape[0]), "hidden": hidden, "chunk_tokens": chunk_tokens if world > 1 else 0,
-                          "backend": "nccl (RCCL)" if world > 1 else "none (one rank: GEMM only)",
-                          "allreduce_bytes": int(out.shape[0]) * hidden * 2 if world > 1 else 0,
-                          "gemm_TFLOPs": 2.0 * out.shape[0] * hidden * H * D / t_op / 1e12 if world == 1 else None}
-        del y, w, proj
-
-    # ---- dominant kernel alone, timed with events on the launch stream ----
+    # ---- dominant kernel alone, timed with events on the launch stream (ahead of the projection below: a large
+    # GEMM leaves the clocks elsewhere than a run of attention steps does) ----
     def timed(fn, iters, median=False):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
         for a, b in evs:
@@ -498,6 +467,38 @@ def main():
                 "kernel_ms": t_attn_ms, "combine_ms": t_comb_ms, "index_build_ms": t_index_ms,
                 "index_build": "by the attention call (inside its launch where the step allows)" if args.index_in_launch
                                else "a launch of its own"}
+
+    # ---- the layer's only exchange step: row-parallel o_proj GEMM + all-reduce of its partial products over the
+    # ranks (linear.py:1358-1359; RCCL over xGMI), chunked over tokens so that a chunk's all-reduce runs beside the
+    # next chunk's GEMM.  Always timed when there is more than one rank (every rank takes part), reported beside
+    # the attention-only `value`, never inside it.
+    if world > 1 or args.oproj:
+        hidden = cfg["hidden"]
+        w = (torch.randn((hidden, H * D), device=dev) * 0.02).bfloat16()
+        chunk_tokens = 8192
+        proj = RowParallelOutputProjection(w, chunk_tokens=chunk_tokens if world > 1 else 0)
+        for _ in range(2):
+            y = proj(out)
+        sync_all()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = proj(out)
+        sync_all()
+        t_op = (time.perf_counter() - t0) / reps
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([t_op], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_op = float(tt.item())
+        extra["oproj_gemm_allreduce_ms"] = t_op * 1e3
+        # (serial sum: the attention of a layer is followed by its projection; no overlap between the two is assumed)
+        extra["layer_ms_with_oproj"] = ms_per_step + t_op * 1e3
+        extra["oproj"] = {"tokens": int(out.shape[0]), "hidden": hidden, "chunk_tokens": chunk_tokens if world > 1 else 0,
+                          "backend": "nccl (RCCL)" if world > 1 else "none (one rank: GEMM only)",
+                          "allreduce_bytes": int(out.shape[0]) * hidden * 2 if world > 1 else 0,
+                          "gemm_TFLOPs": 2.0 * out.shape[0] * hidden * H * D / t_op / 1e12 if world == 1 else None}
+        del y, w, proj
 
     if not args.no_baselines and rank == 0 and not fp8:
         # dense-causal baselines at the same shape (attention-op level)
