@@ -43,7 +43,14 @@ constexpr int kDN = 64;        // keys per tile
 constexpr int kDRowB = 256;    // bytes per K / V row in LDS (head size 128, 16-bit)
 constexpr int kDTile = kDN * kDRowB;  // one tensor of one tile: 16 KB
 constexpr float kDMinusBig = -1.0e30f;
-constexpr int kQkAhead = 4;  // K fragments in flight in the first product (at most 4: the wait counts are written out)
+#ifndef TMX_DENSE_QK_AHEAD
+#define TMX_DENSE_QK_AHEAD 4
+#endif
+constexpr int kQkAhead = TMX_DENSE_QK_AHEAD;  // K fragments in flight in the first product (1..8: the wait counts are written out)
+#ifndef TMX_DENSE_PV_AHEAD
+#define TMX_DENSE_PV_AHEAD 3
+#endif
+constexpr int kPvAhead = TMX_DENSE_PV_AHEAD;  // V fragments (two transposed reads each) in flight ahead of the second product's instruction (1..7)
 constexpr float kDSlack = 8.0f;  // the running maximum moves only when a tile exceeds it by more than this (log2 units)
 
 template <typename T>
@@ -89,6 +96,13 @@ __device__ __forceinline__ void lds_store_b128(unsigned addr, uint4 v) {
 }
 __device__ __forceinline__ s16x4_t lds_tr16(unsigned addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)addr);
+}
+// The transposed 8-byte read at a per-lane address plus a compile-time offset, like lds_b128_at: neither reordered nor
+// waited for by the compiler.
+template <unsigned OFF>
+__device__ __forceinline__ void lds_tr16_at(int addr, s16x4_t& dst) {
+  static_assert(OFF < 65536, "the offset field has 16 bits");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 
 // KV8: K and V are an fp8 (e4m3fn) paged cache; a thread then carries 16 bytes (16 values) of a row per tensor
@@ -364,14 +378,43 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
           for (int i = 0; i < 16; ++i) {
             u32x4_t& f = kf[i % kQkAhead];
             const int left = 15 - i < kQkAhead - 1 ? 15 - i : kQkAhead - 1;  // reads that may stay in flight
+            static_assert(kQkAhead >= 1 && kQkAhead <= 8, "wait counts are written out up to 7");
             if (left == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f)::"memory");
             else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f)::"memory");
             else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f)::"memory");
-            else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f)::"memory");
+            else if (left == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f)::"memory");
+            else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f)::"memory");
+            else if (left == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(f)::"memory");
+            else if (left == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f)::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(f)::"memory");
             s[i >> 3] = mfma_qk<BF16>(__builtin_bit_cast(uint4, f), qf[i & 7], (i & 7) == 0 ? zero : s[i >> 3]);
             if (i + kQkAhead < 16) rd(i + kQkAhead, f);
           }
         }
+        // The V^T fragments of the second product, read the same way: fragment i (k-step i >> 2 of the tile's four,
+        // column block i & 3) is two transposed 8-byte reads; kPvAhead fragments are in flight ahead of the
+        // instruction that takes one, the first ones from here on, behind the maximum and the exponentials.  (Left
+        // to itself the compiler issues a fragment's reads right in front of its instruction and waits: every one
+        // of the sixteen then exposes the LDS latency.)
+        s16x4_t vlo[kPvAhead + 1], vhi[kPvAhead + 1];
+        auto rdv = [&](int i, s16x4_t& lo, s16x4_t& hi) {
+          const int a = voff[i & 3];
+          if ((i >> 2) == 0) {
+            lds_tr16_at<cur>(a, lo);
+            lds_tr16_at<cur + 8 * kDRowB>(a, hi);
+          } else if ((i >> 2) == 1) {
+            lds_tr16_at<cur + 16 * kDRowB>(a, lo);
+            lds_tr16_at<cur + 24 * kDRowB>(a, hi);
+          } else if ((i >> 2) == 2) {
+            lds_tr16_at<cur + 32 * kDRowB>(a, lo);
+            lds_tr16_at<cur + 40 * kDRowB>(a, hi);
+          } else {
+            lds_tr16_at<cur + 48 * kDRowB>(a, lo);
+            lds_tr16_at<cur + 56 * kDRowB>(a, hi);
+          }
+        };
+#pragma unroll
+        for (int i = 0; i < kPvAhead; ++i) rdv(i, vlo[i], vhi[i]);
         // register i of block kb is key 64 t + 32 kb + (i & 3) + 8 (i >> 2) + 4 h
         const int key0 = kDN * t + 4 * h;
         if (kDN * t + kDN - 1 > w_pos0) {  // the tile reaches past some row's diagonal
@@ -422,18 +465,24 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
         l_run += psum;
         // ---- O^T += V^T P^T: element j of lane half h in k-step u of block kb is key 32 kb + 16 u + 8 (j >> 2) + 4 h + (j & 3) ----
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const unsigned vb = cur + (32 * kb + 16 * u) * kDRowB;
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-              const s16x4_t lo4 = lds_tr16(vb + voff[db]);
-              const s16x4_t hi4 = lds_tr16(vb + voff[db] + 8 * kDRowB);
-              const uint4 vf = __builtin_bit_cast(uint4, (s16x8_t)__builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
-              acc[db] = mfma_pv(vf, pf[kb][u], acc[db]);
-            }
-          }
+        for (int i = 0; i < 16; ++i) {
+          constexpr int R = kPvAhead + 1;
+          if (i + kPvAhead < 16) rdv(i + kPvAhead, vlo[(i + kPvAhead) % R], vhi[(i + kPvAhead) % R]);
+          s16x4_t& lo4 = vlo[i % R];
+          s16x4_t& hi4 = vhi[i % R];
+          const int left = 15 - i < kPvAhead ? 15 - i : kPvAhead;  // fragments that may stay in flight (two reads each)
+          static_assert(kPvAhead >= 1 && kPvAhead <= 7, "the counter has four bits");
+          if (left == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo4), "+v"(hi4)::"memory");
+          else if (left == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo4), "+v"(hi4)::"memory");
+          else if (left == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lo4), "+v"(hi4)::"memory");
+          else if (left == 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(lo4), "+v"(hi4)::"memory");
+          else if (left == 4) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(lo4), "+v"(hi4)::"memory");
+          else if (left == 5) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(lo4), "+v"(hi4)::"memory");
+          else if (left == 6) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(lo4), "+v"(hi4)::"memory");
+          else asm volatile("s_waitcnt lgkmcnt(14)" : "+v"(lo4), "+v"(hi4)::"memory");
+          const uint4 vf = __builtin_bit_cast(uint4, (s16x8_t)__builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+          acc[i & 3] = mfma_pv(vf, pf[i >> 3][(i >> 2) & 1], acc[i & 3]);
+        }
       }
 
       if (more) stage(nxt, kreg, vreg);
