@@ -94,9 +94,16 @@ __device__ __forceinline__ int first_item_of(int total_pieces, int total_parts, 
 }
 
 // Pass 2 for one q-block: entries e0, e0 + estep, ... of its tile list and pieces pc0, pc0 + estep, ...
+// The physical pages of a tile's two 16-key halves (keys past the end share the last page).
+__device__ __forceinline__ int2 tile_pages_of(const IndexParams& p, int b, int n, int tile) {
+  const int32_t* bt = p.block_table + (long long)b * p.block_table_stride;
+  return make_int2(bt[(tile * p.block_n) >> p.page_shift], bt[imin(tile * p.block_n + 16, n - 1) >> p.page_shift]);
+}
+
+// `pre`: the pages of entries e0, e0 + estep, e0 + 2 estep, e0 + 3 estep, looked up by the caller earlier (or NULL).
 __device__ __forceinline__ void fill_qblock(const IndexParams& p, int qb, int b, int r0, int n, int ctx, int q_row0,
                                             const TileRanges& tr, int cnt, int start, int first_item, int slot0,
-                                            int e0, int estep) {
+                                            int e0, int estep, const int2* pre = nullptr) {
   // four entries at a time: their block-table lookups are all in flight before the first store (one trip to
   // memory per group instead of one per entry)
   for (int e = e0; e < cnt; e += 4 * estep) {
@@ -110,7 +117,10 @@ __device__ __forceinline__ void fill_qblock(const IndexParams& p, int qb, int b,
       tile[u] = ok[u] ? tr.tile_at(ee) : 0;
       pg[u] = make_int2(0, 0);
     }
-    if (p.tile_pages != nullptr) {
+    if (p.tile_pages != nullptr && pre != nullptr && e == e0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pg[u] = pre[u];
+    } else if (p.tile_pages != nullptr) {
       // physical pages of the tile's two 16-key halves (keys past the end share the last page)
       const int32_t* bt = p.block_table + (long long)b * p.block_table_stride;
 #pragma unroll
@@ -219,6 +229,9 @@ __device__ __forceinline__ void index_scan_body(const IndexParams& p, IndexScanS
   Int4 kv[kRounds], ke[kRounds];
   int kb[kRounds], kr0[kRounds];
   TileRanges ktr[kRounds];
+  // ... and the pages of the first four entries of its tile list (a sparse q-block lists three tiles): asked for
+  // ahead of the scan, so that the trip to the block table is over when the list is written
+  int2 kpg[kRounds][4];
 #pragma unroll
   for (int k = 0; k < kRounds; ++k) {
     kv[k] = Int4{0, 0, 0, 0};
@@ -226,9 +239,11 @@ __device__ __forceinline__ void index_scan_body(const IndexParams& p, IndexScanS
     kb[k] = 0;
     kr0[k] = 0;
     ktr[k] = TileRanges{0, -1, 0, -1};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kpg[k][u] = make_int2(0, 0);
   }
   const bool one_pass = p.fused && R <= 1024;
-  auto count_round = [&](int base, Int4& v, Int4& e, int& b, int& r0, TileRanges& tr_own) {
+  auto count_round = [&](int base, Int4& v, Int4& e, int& b, int& r0, TileRanges& tr_own, int2 (&pg)[4]) {
     const int qb = base + tid;
     v = Int4{0, 0, 0, 0};
     b = 0;
@@ -251,6 +266,10 @@ __device__ __forceinline__ void index_scan_body(const IndexParams& p, IndexScanS
       const int pieces = cnt <= p.chunk ? 1 : ceil_div(cnt, p.chunk);
       v = Int4{cnt, pieces, pieces > 1 ? pieces : 0, pieces > 1 ? 1 : 0};
       max_tiles = imax(max_tiles, cnt);
+      if (one_pass && p.tile_pages != nullptr && cnt <= kLongList) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pg[u] = u < cnt ? tile_pages_of(p, b, n, tr_own.tile_at(u)) : make_int2(0, 0);
+      }
     }
     ISTAMP(7);
     Int4 tot;
@@ -271,9 +290,9 @@ __device__ __forceinline__ void index_scan_body(const IndexParams& p, IndexScanS
   if (one_pass) {
 #pragma unroll
     for (int k = 0; k < kRounds; ++k)
-      if (k * NT < R) count_round(k * NT, kv[k], ke[k], kb[k], kr0[k], ktr[k]);
+      if (k * NT < R) count_round(k * NT, kv[k], ke[k], kb[k], kr0[k], ktr[k], kpg[k]);
   } else {
-    for (int base = 0; base < R; base += NT) count_round(base, kv[0], ke[0], kb[0], kr0[0], ktr[0]);
+    for (int base = 0; base < R; base += NT) count_round(base, kv[0], ke[0], kb[0], kr0[0], ktr[0], kpg[0]);
   }
   if (one_pass) {
     // run holds the totals, this thread still holds its q-blocks' numbers
@@ -289,7 +308,7 @@ __device__ __forceinline__ void index_scan_body(const IndexParams& p, IndexScanS
         is_long[k] = kv[k].x > kLongList;
         if (!is_long[k])
           fill_qblock(p, qb, kb[k], kr0[k], n, ctx, rq.x + kr0[k], ktr[k], kv[k].x, ke[k].x,
-                      first_item_of(run.y, run.z, ke[k].y, ke[k].z, kv[k].y), ke[k].z, 0, 1);
+                      first_item_of(run.y, run.z, ke[k].y, ke[k].z, kv[k].y), ke[k].z, 0, 1, kpg[k]);
       }
       if (is_long[k]) {
         const int at = atomicAdd(&sh.num_long, 1);
@@ -303,10 +322,17 @@ __device__ __forceinline__ void index_scan_body(const IndexParams& p, IndexScanS
         }
       }
     }
-    __syncthreads();
+    // (a barrier for the LDS table only: the short lists' stores drain while the long lists are written)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     ISTAMP(3);
     const int num_long = sh.num_long;
-    for (int k = 0; k < imin(num_long, 64); ++k) {
+    // The long lists are written side by side: the threads are dealt round the lists (a power of two of them at a
+    // time, so that NT divides evenly), every thread takes entries of ONE list -- the lookups of all lists make one
+    // trip to the block table instead of one trip per list.
+    const int listed_long = imin(num_long, 64);
+    int side = 1;
+    while (side < listed_long) side <<= 1;
+    for (int k = tid & (side - 1); k < listed_long; k += side) {
       const int lq = sh.long_list[k][0], lb = sh.long_list[k][1], lr0 = sh.long_list[k][2];
       const int4 rq = request(lb);
       const int ql = rq.y, n = rq.z, nf = rq.w;
@@ -317,7 +343,8 @@ __device__ __forceinline__ void index_scan_body(const IndexParams& p, IndexScanS
       const int cnt = tr.count();
       const int pieces = imax(1, ceil_div(cnt, p.chunk));
       fill_qblock(p, lq, lb, lr0, n, ctx, rq.x + lr0, tr, cnt, sh.long_list[k][3],
-                  first_item_of(run.y, run.z, sh.long_list[k][4], sh.long_list[k][5], pieces), sh.long_list[k][5], tid, NT);
+                  first_item_of(run.y, run.z, sh.long_list[k][4], sh.long_list[k][5], pieces), sh.long_list[k][5],
+                  tid / side, NT / side);
     }
     if (num_long > 64) {
       // more long lists than the table holds: the remaining ones are written by their own threads
