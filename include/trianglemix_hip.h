@@ -351,7 +351,10 @@ int tmx_static_workspace_warmup(void);
  * lies among the trailing dense rows, trianglemix_attention.py:126-129, provided last >= 2) and what a layer
  * outside the triangle set computes.  Paged K/V, head_dim 128, query-head groups that are multiples of 4;
  * 16-bit or fp8 (e4m3fn) caches; k_new / v_new / cache_slots as in tmx_attention_args_t (row b = request b's
- * newest key / value; the call then also stores it to its slot).
+ * newest key / value, of the q dtype; the call then also stores it to its slot).  With an fp8 cache the stored
+ * bytes are fp8(x / scale), exactly what tmx_reshape_and_cache_fp8 stores, and the row's own key / value is
+ * attended to as the cache holds it -- the call equals that write followed by the attention over the cache
+ * (the reference's pair, rocm_attn.py:345-358), bit for bit, in one launch.
  *
  * The launch depends on the batch size alone.  Its pieces are laid out on the device, by every workgroup for
  * itself, from seq_lens: with T the 32-key tiles of all requests, pieces are P = max(8, ceil(T * units / slots))
@@ -382,7 +385,7 @@ typedef struct tmx_decode_args_t {
   int32_t page_size;
   int32_t kv_dtype;     /* 0 / io_dtype, or TMX_FP8_E4M3 */
   float k_scale, v_scale;
-  const void* k_new;    /* optional (16-bit cache): [batch, num_kv_heads, head_dim], row b = request b's newest key */
+  const void* k_new;    /* optional: [batch, num_kv_heads, head_dim] of the q dtype, row b = request b's newest key */
   const void* v_new;
   int64_t new_stride_t, new_stride_h;
   const int64_t* cache_slots; /* optional, with k_new / v_new: (device) [batch], negative = skipped */

@@ -1598,6 +1598,71 @@ def test_decode_attention_with_a_fixed_launch_shape(monkeypatch, case):
         ops.decode_attention(_to_dev(q, dtype), kc, vc, out, bt, sld, scale, small)
 
 
+@pytest.mark.parametrize("binding", ["torch", "ctypes"])
+@pytest.mark.parametrize("dtype,scales,heads", [(torch.bfloat16, (0.75, 1.5), (8, 2)), (torch.float16, (1.0, 1.0), (16, 2)),
+                                                (torch.bfloat16, (0.02, 0.04), (8, 1))])
+def test_decode_attention_writes_an_fp8_cache_itself(monkeypatch, binding, dtype, scales, heads):
+    """A decode step out of an fp8 cache with the step's rows handed to the launch (k_new / v_new / cache_slots): the
+    launch quantises and stores them and attends to the row's own key as the cache holds it.  The cache bytes and the
+    output must be IDENTICAL to tmx_reshape_and_cache_fp8 followed by the launch over the cache (the reference's
+    order, rocm_attn.py:345-358), and the rows the oracle's.  Scales that saturate some values (0.02: |x| / scale
+    beyond 448) are part of it; padding rows (slot -1, length 0) stay untouched."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "_BINDING", binding)
+    (H, Hkv), D, page = heads, 128, 16
+    seq_lens = [1, 2, 16, 17, 32, 33, 64, 65, 0, 129, 700, 2049, 4100, 0]
+    B = len(seq_lens)
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else (lambda x: np.float16(x).astype(np.float32))
+    q, ks, vs = _rand_case(7100 + H, [1] * B, [max(s, 1) for s in seq_lens], H, Hkv, D)
+    q, ks, vs = rnd(q), [rnd(k[:s]) for k, s in zip(ks, seq_lens)], [rnd(v[:s]) for v, s in zip(vs, seq_lens)]
+    # the cache holds every sequence's context (all keys but the last); the last key is the step's own row
+    ctx_k = [k[:max(s - 1, 0)] for k, s in zip(ks, seq_lens)]
+    ctx_v = [v[:max(s - 1, 0)] for v, s in zip(vs, seq_lens)]
+    kc, vc, bt, last_slot = _paged_decode_batch(seq_lens, Hkv, D, page, dtype, 9, ks, vs, fp8_scales=scales)
+    # (the helper wrote all keys: wipe the step's own slots so that only the launch under test can fill them)
+    k_rows = torch.zeros((B, Hkv, D), dtype=dtype, device=DEV)
+    v_rows = torch.zeros((B, Hkv, D), dtype=dtype, device=DEV)
+    for b, s_ in enumerate(seq_lens):
+        if s_ > 0:
+            k_rows[b] = _to_dev(ks[b][s_ - 1], dtype)
+            v_rows[b] = _to_dev(vs[b][s_ - 1], dtype)
+    slots = torch.from_numpy(last_slot).to(DEV)
+    live_slots = slots[slots >= 0]
+    kc_flat, vc_flat = kc.view(-1, Hkv, D), vc.view(-1, Hkv, D)
+    want_k, want_v = kc_flat[live_slots].clone(), vc_flat[live_slots].clone()   # what reshape_and_cache_fp8 stored
+    kc_flat[live_slots] = 0x55
+    vc_flat[live_slots] = 0x55
+    sld = torch.tensor(seq_lens, dtype=torch.int32, device=DEV)
+    ws = ops.decode_workspace(B, H, Hkv, D, DEV, True)
+    scale = D ** -0.5
+    qd = _to_dev(q, dtype)
+    # route A: the reference's order on a copy of the cache
+    kc_a, vc_a = kc.clone(), vc.clone()
+    ops.reshape_and_cache_fp8(k_rows, v_rows, kc_a, vc_a, slots, *scales)
+    out_a = torch.full((B, H, D), 7.0, dtype=torch.float32, device=DEV)
+    ops.decode_attention(qd, kc_a, vc_a, out_a, bt, sld, scale, ws, k_scale=scales[0], v_scale=scales[1])
+    # route B: one launch
+    out_b = torch.full((B, H, D), 7.0, dtype=torch.float32, device=DEV)
+    ops.decode_attention(qd, kc, vc, out_b, bt, sld, scale, ws, k_scale=scales[0], v_scale=scales[1],
+                         k_new=k_rows, v_new=v_rows, cache_slots=slots)
+    torch.cuda.synchronize()
+    assert torch.equal(kc.view(torch.uint8), kc_a.view(torch.uint8)) and torch.equal(vc.view(torch.uint8), vc_a.view(torch.uint8))
+    assert torch.equal(kc_flat[live_slots].view(torch.uint8), want_k.view(torch.uint8))
+    assert torch.equal(vc_flat[live_slots].view(torch.uint8), want_v.view(torch.uint8))
+    assert torch.equal(out_a, out_b)
+    live = [b for b, s_ in enumerate(seq_lens) if s_ > 0]
+    pad = [b for b, s_ in enumerate(seq_lens) if s_ == 0]
+    got = out_b.cpu().numpy()
+    assert np.all(got[pad] == 7.0)
+    seen = lambda x, sc: rnd(orc.fp8_cache_roundtrip(x, sc).astype(np.float32))  # noqa: E731
+    ks8, vs8 = [seen(k, scales[0]) for k in ks], [seen(v, scales[1]) for v in vs]
+    ref = orc.varlen_gqa_attention(q[live], lambda i: ks8[live[i]], lambda i: vs8[live[i]], np.arange(len(live) + 1),
+                                   [seq_lens[b] for b in live], scale, "causal", 0, 0, 0)
+    assert_close(got[live], ref, f"decode rows, fixed launch shape, fp8 cache written by the launch, {str(dtype)[6:]}",
+                 info=(binding, scales, heads))
+    del ctx_k, ctx_v
+
+
 def test_decode_step_replays_under_a_graph():
     """A decode step through the backend, captured in a graph (torch.cuda.graph) the way the model runner does it:
     metadata from build_for_cudagraph_capture over persistent buffers, a warm-up call, the capture, then replays after

@@ -465,7 +465,8 @@ class TriangleMixAttentionImpl(_ImplBase):
                               k_scale: float = 1.0, v_scale: float = 1.0):
         """A step of one-row requests through ``tmx_decode_attention``: no index, nothing derived on the host from the
         requests' lengths -- the call replays under a graph with whatever ``seq_lens`` / ``block_table`` /
-        ``slot_mapping`` hold by then.  A 16-bit cache gets the step's rows from the same launch."""
+        ``slot_mapping`` hold by then.  The cache gets the step's rows from the same launch (an fp8 cache: quantised
+        on the way, and the row's own key attended to as the cache holds it)."""
         n_tok = m.num_actual_tokens
         fp8 = self.fp8_cache
         if m.builder is not None:
@@ -473,7 +474,7 @@ class TriangleMixAttentionImpl(_ImplBase):
         else:
             ws = ops.decode_workspace(n_tok, self.num_heads, self.num_kv_heads, self.head_size, q.device, fp8)
         k_rows = v_rows = slots = None
-        if writes_cache and not fp8:
+        if writes_cache:
             k_rows = key[:n_tok].view(n_tok, self.num_kv_heads, self.head_size)
             v_rows = value[:n_tok].view(n_tok, self.num_kv_heads, self.head_size)
             slots = m.slot_mapping[:n_tok]
@@ -489,11 +490,16 @@ class TriangleMixAttentionImpl(_ImplBase):
         n_tok = m.num_actual_tokens
         k_scale = float(getattr(layer, "_k_scale_float", 1.0))
         v_scale = float(getattr(layer, "_v_scale_float", 1.0))
-        if self.kv_sharing_target_layer_name is None and key is not None and value is not None:
+        writes_cache = self.kv_sharing_target_layer_name is None and key is not None and value is not None
+        out = output.view(-1, self.num_heads, self.head_size)[:n_tok]
+        if m.uniform_decode and self._decode_fixed_ok() and _CACHE_WRITE_MODE == "fused":
+            # decode steps: ONE launch quantises and stores the step's rows and attends
+            return self._forward_decode_fixed(q, key, value, key_cache, value_cache, m, out, output, writes_cache,
+                                              k_scale=k_scale, v_scale=v_scale)
+        if writes_cache:
             ops.reshape_and_cache_fp8(key[:n_tok].view(n_tok, self.num_kv_heads, self.head_size),
                                       value[:n_tok].view(n_tok, self.num_kv_heads, self.head_size), key_cache, value_cache,
                                       m.slot_mapping[:n_tok], k_scale, v_scale)
-        out = output.view(-1, self.num_heads, self.head_size)[:n_tok]
         if m.uniform_decode and self._decode_fixed_ok():
             return self._forward_decode_fixed(q, key, value, key_cache, value_cache, m, out, output, False,
                                               k_scale=k_scale, v_scale=v_scale)

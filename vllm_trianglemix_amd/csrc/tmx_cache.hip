@@ -97,25 +97,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_fp8_kernel(
     const int64_t dst = page * stride_page + in_pg * stride_t + (int64_t)h * stride_h + cc * 8;
     const uint4 kin = *reinterpret_cast<const uint4*>(key + src);
     const uint4 vin = *reinterpret_cast<const uint4*>(value + src);
-    const uint16_t* kp = reinterpret_cast<const uint16_t*>(&kin);
-    const uint16_t* vp = reinterpret_cast<const uint16_t*>(&vin);
-    uint2 ko, vo;
-    uint32_t* kw = reinterpret_cast<uint32_t*>(&ko);
-    uint32_t* vw = reinterpret_cast<uint32_t*>(&vo);
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-      int a = 0, b = 0;
-      a = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(kp + 4 * w, in_dtype) / k_scale),
-                                          sat448(load16(kp + 4 * w + 1, in_dtype) / k_scale), a, false);
-      a = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(kp + 4 * w + 2, in_dtype) / k_scale),
-                                          sat448(load16(kp + 4 * w + 3, in_dtype) / k_scale), a, true);
-      b = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(vp + 4 * w, in_dtype) / v_scale),
-                                          sat448(load16(vp + 4 * w + 1, in_dtype) / v_scale), b, false);
-      b = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(load16(vp + 4 * w + 2, in_dtype) / v_scale),
-                                          sat448(load16(vp + 4 * w + 3, in_dtype) / v_scale), b, true);
-      kw[w] = (uint32_t)a;
-      vw[w] = (uint32_t)b;
-    }
+    const uint2 ko = quant8_fp8(kin, in_dtype == TMX_BF16, k_scale), vo = quant8_fp8(vin, in_dtype == TMX_BF16, v_scale);
     *reinterpret_cast<uint2*>(key_cache + dst) = ko;
     *reinterpret_cast<uint2*>(value_cache + dst) = vo;
   }

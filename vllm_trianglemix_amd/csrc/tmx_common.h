@@ -121,6 +121,38 @@ TMX_HD int same_count_run(int mode, int k, int ctx, int q_len, int n_full, int s
   return k_end >= k ? (int)(k_end - k + 1) : 1;
 }
 
+#if defined(__HIPCC__)
+// Eight 16-bit values (bf16 or fp16, 16 bytes) as eight fp8 (e4m3fn) bytes of an fp8 K/V cache: fp8(x / scale), round
+// to nearest even, finite values saturating at +-448, NaN staying NaN (the reference's scaled conversion,
+// csrc/quantization/fp8/amd/quant_utils.cuh, as reshape_and_cache_flash applies it, csrc/cache_kernels.cu:282-355).
+// ONE definition for the stand-alone cache write and for the kernels that write the cache themselves: their bytes
+// must be the same.
+__device__ __forceinline__ uint2 quant8_fp8(uint4 in, bool bf16, float scale) {
+  const uint32_t w[4] = {in.x, in.y, in.z, in.w};
+  float f[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (bf16) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    } else {
+      typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+      const h2_t h = __builtin_bit_cast(h2_t, w[i]);
+      f[2 * i] = (float)h[0];
+      f[2 * i + 1] = (float)h[1];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = fminf(fmaxf(f[i] / scale, -448.f), 448.f);
+  int a = 0, b = 0;
+  a = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], a, false);
+  a = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], a, true);
+  b = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], b, false);
+  b = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], b, true);
+  return make_uint2((uint32_t)a, (uint32_t)b);
+}
+#endif
+
 void set_error(const char* fmt, ...);
 
 #define TMX_CHECK_ARG(cond, ...)      \

@@ -179,20 +179,26 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
     const int stride = (int)gridDim.x * 256;
     const uint16_t* kn = reinterpret_cast<const uint16_t*>(p.k_new);
     const uint16_t* vn = reinterpret_cast<const uint16_t*>(p.v_new);
-    uint16_t* kc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.k));
-    uint16_t* vc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.v));
     for (int u = (int)blockIdx.x * 256 + tid; u < units; u += stride) {
       const int c = u % CPR, th = u / CPR;
       const int h = th % p.Hkv, t = th / p.Hkv;
       const long long slot = p.cache_slots[t];
       if (slot < 0) continue;
       const long long src = (long long)t * p.new_stride_t + (long long)h * p.new_stride_h + 8 * c;
+      // (cache strides: elements of the cache's type -- bytes for an fp8 cache)
       const long long dst = (slot >> p.page_shift) * p.kv_stride_page + (slot & (p.page_size - 1)) * (long long)p.kv_stride_t +
                             (long long)h * p.kv_stride_h + 8 * c;
       const uint4 kx = *reinterpret_cast<const uint4*>(kn + src);
       const uint4 vx = *reinterpret_cast<const uint4*>(vn + src);
-      *reinterpret_cast<uint4*>(kc + dst) = kx;
-      *reinterpret_cast<uint4*>(vc + dst) = vx;
+      if constexpr (KV8) {
+        // an fp8 cache: the quantising write (the reference's reshape_and_cache_flash with kv_cache_dtype "fp8"),
+        // the same bytes as tmx_reshape_and_cache_fp8 stores
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(const_cast<void*>(p.k)) + dst) = quant8_fp8(kx, BF16, p.k_scale);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(const_cast<void*>(p.v)) + dst) = quant8_fp8(vx, BF16, p.v_scale);
+      } else {
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(const_cast<void*>(p.k)) + dst) = kx;
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(const_cast<void*>(p.v)) + dst) = vx;
+      }
     }
   }
 
@@ -251,7 +257,8 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
   const long long krow0 = PAGED ? 0 : (long long)dcs(p.cu_k + b);
   const int32_t* const bt = PAGED ? p.block_table + (long long)b * p.block_table_stride : nullptr;
   // two sources: keys from position ctx on (the step's own row) come from k_new / v_new
-  const bool two = PAGED && !KV8 && p.k_new != nullptr;
+  // (out of an fp8 cache the step's own key is read as the cache will hold it: its row quantised on the way in)
+  const bool two = PAGED && p.k_new != nullptr;
   const int ctx = n - 1;
   const long long new_off = two ? 2ll * ((long long)q_tok * p.new_stride_t + (long long)kvh * p.new_stride_h) : 0;
 
@@ -295,11 +302,36 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
       if constexpr (PAGED) return base + page_off + (long long)(kk & (p.page_size - 1)) * kv_row_bytes;
       else return base + (krow0 + kk) * kv_row_bytes;
     };
-    const char* kr = row_ptr(kbase, p.k_new, jb + c16) + 16 * g;
+    if constexpr (KV8) {
+      // the step's own row is 16-bit: its fp8 image, byte for byte what the cache write stores (16 columns of K
+      // per load, 8 columns of V)
+      const bool k_fresh = two && imin(jb + c16, n - 1) >= ctx;
+      const char* kr = row_ptr(kbase, p.k_new, jb + c16);
 #pragma unroll
-    for (int x = 0; x < KL; ++x) r.k[x] = *reinterpret_cast<const uint4*>(kr + 64 * x);
+      for (int x = 0; x < KL; ++x) {
+        if (k_fresh) {
+          const char* src = kr + 2 * (16 * g + 64 * x);
+          const uint2 q0 = quant8_fp8(*reinterpret_cast<const uint4*>(src), BF16, p.k_scale);
+          const uint2 q1 = quant8_fp8(*reinterpret_cast<const uint4*>(src + 16), BF16, p.k_scale);
+          r.k[x] = make_uint4(q0.x, q0.y, q1.x, q1.y);
+        } else {
+          r.k[x] = *reinterpret_cast<const uint4*>(kr + 16 * g + 64 * x);
+        }
+      }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = *reinterpret_cast<const VRaw*>(row_ptr(vbase, p.v_new, jb + 4 * g + i) + KVB * 8 * c16);
+      for (int i = 0; i < 4; ++i) {
+        const bool v_fresh = two && imin(jb + 4 * g + i, n - 1) >= ctx;
+        const char* vr = row_ptr(vbase, p.v_new, jb + 4 * g + i);
+        if (v_fresh) r.v[i] = quant8_fp8(*reinterpret_cast<const uint4*>(vr + 2 * 8 * c16), BF16, p.v_scale);
+        else r.v[i] = *reinterpret_cast<const VRaw*>(vr + 8 * c16);
+      }
+    } else {
+      const char* kr = row_ptr(kbase, p.k_new, jb + c16) + 16 * g;
+#pragma unroll
+      for (int x = 0; x < KL; ++x) r.k[x] = *reinterpret_cast<const uint4*>(kr + 64 * x);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r.v[i] = *reinterpret_cast<const VRaw*>(row_ptr(vbase, p.v_new, jb + 4 * g + i) + KVB * 8 * c16);
+    }
   };
 
   float m_run = kDcMinusBig, l_run = 0.f;  // of head c16 over the keys of lane group g (lanes c16 < HW)
@@ -763,7 +795,6 @@ extern "C" int tmx_decode_attention(const tmx_decode_args_t* a, void* stream) {
   const bool two_src = a->k_new != nullptr || a->v_new != nullptr;
   if (two_src) {
     TMX_CHECK_ARG(a->k_new != nullptr && a->v_new != nullptr, "tmx_decode_attention: k_new and v_new go together");
-    TMX_CHECK_SUPPORTED(!fp8, "tmx_decode_attention: k_new / v_new need a 16-bit cache");
     TMX_CHECK_ARG(dc_aligned16(a->k_new) && dc_aligned16(a->v_new) && a->new_stride_t % 8 == 0 && a->new_stride_h % 8 == 0 &&
                       a->new_stride_t >= 0 && a->new_stride_h >= 0 && a->new_stride_t < (1ll << 24) && a->new_stride_h <= lim,
                   "tmx_decode_attention: k_new / v_new must be 16-byte aligned with strides that are multiples of 8 elements");

@@ -344,11 +344,11 @@ void decode_attention(Tensor& out, const Tensor& query, const Tensor& key_cache,
   a.v_scale = fp8 ? (float)v_scale : 1.0f;
   TORCH_CHECK(k_new.has_value() == v_new.has_value(), "trianglemix: k_new and v_new go together");
   if (k_new.has_value()) {
-    TORCH_CHECK(!fp8 && k_new->dim() == 3 && k_new->sizes() == v_new->sizes() && k_new->strides() == v_new->strides() &&
+    TORCH_CHECK(k_new->dim() == 3 && k_new->sizes() == v_new->sizes() && k_new->strides() == v_new->strides() &&
                     k_new->stride(2) == 1 && k_new->scalar_type() == query.scalar_type() &&
                     v_new->scalar_type() == query.scalar_type() && k_new->size(0) >= B &&
                     k_new->size(1) == key_cache.size(2) && k_new->size(2) == query.size(2),
-                "trianglemix: k_new / v_new must be [B, Hkv, D] rows of the q dtype with equal strides (16-bit cache)");
+                "trianglemix: k_new / v_new must be [B, Hkv, D] rows of the q dtype with equal strides");
     a.k_new = k_new->data_ptr();
     a.v_new = v_new->data_ptr();
     a.new_stride_t = k_new->stride(0);

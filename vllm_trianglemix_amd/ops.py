@@ -528,7 +528,9 @@ def decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: tor
     pieces are laid out on the device from ``seq_lens``), so the call can be captured in a HIP graph
     (``torch.cuda.graph``) and replayed after ``seq_lens`` / ``block_table`` / the caches changed in place.
     ``seq_lens[b] <= 0`` marks a padding row.  ``workspace``: :func:`decode_workspace` for this batch size.
-    ``k_new`` / ``v_new`` / ``cache_slots``: the step's own rows, stored to their slots by the same launch."""
+    ``k_new`` / ``v_new`` / ``cache_slots``: the step's own rows, stored to their slots by the same launch -- into
+    an fp8 cache as ``fp8(x / scale)``, the bytes ``reshape_and_cache_fp8`` stores, and the row's own key is then
+    attended to as the cache holds it."""
     if workspace is None or workspace[0] is None or workspace[1] is None:
         raise RuntimeError("decode_attention needs its work area (ops.decode_workspace for the batch size)")
     C = _op_binding()
@@ -571,10 +573,10 @@ def decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: tor
     if k_new is not None:
         _require_gpu(k_new, "k_new")
         _require_gpu(v_new, "v_new")
-        if (fp8 or k_new.dim() != 3 or k_new.shape != v_new.shape or k_new.stride() != v_new.stride() or k_new.stride(2) != 1
+        if (k_new.dim() != 3 or k_new.shape != v_new.shape or k_new.stride() != v_new.stride() or k_new.stride(2) != 1
                 or k_new.dtype != q.dtype or v_new.dtype != q.dtype or k_new.shape[0] < B
                 or tuple(k_new.shape[1:]) != (a.num_kv_heads, D)):
-            raise RuntimeError("k_new / v_new must be [B, Hkv, D] rows of the q dtype with equal strides (16-bit cache)")
+            raise RuntimeError("k_new / v_new must be [B, Hkv, D] rows of the q dtype with equal strides")
         a.k_new, a.v_new, a.new_stride_t, a.new_stride_h = k_new.data_ptr(), v_new.data_ptr(), k_new.stride(0), k_new.stride(1)
     a.cache_slots = None
     if cache_slots is not None:
