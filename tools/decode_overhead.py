@@ -92,6 +92,53 @@ def run(B, N):
               f"({w / LAYERS:6.1f} per layer)")
 
 
+def run_fp8_write(B, N):
+    """Decode layers out of an fp8 cache, the step's K/V rows written by a launch of their own (the reference's order)
+    or by the attention launch itself; eager and as one graph replay per step."""
+    g = torch.Generator().manual_seed(0)
+    nblk = B * (N // PAGE)
+    kc = (torch.randn((nblk, PAGE, Hkv, D), generator=g) * 8).to(dev).to(torch.float8_e4m3fn)
+    vc = (torch.randn((nblk, PAGE, Hkv, D), generator=g) * 8).to(dev).to(torch.float8_e4m3fn)
+    bt = torch.randperm(nblk, generator=g).to(torch.int32).view(B, -1).to(dev)
+    q = torch.randn((B, H, D), generator=g).to(dev).bfloat16()
+    kn = torch.randn((B, Hkv, D), generator=g).to(dev).bfloat16()
+    vn = torch.randn((B, Hkv, D), generator=g).to(dev).bfloat16()
+    out = torch.empty_like(q)
+    sld = torch.full((B,), N, dtype=torch.int32, device=dev)
+    slots = (bt[:, (N - 1) // PAGE].to(torch.int64) * PAGE + (N - 1) % PAGE).contiguous()
+    ws = ops.decode_workspace(B, H, Hkv, D, dev, True)
+
+    def separate():
+        for _ in range(LAYERS):
+            ops.reshape_and_cache_fp8(kn, vn, kc, vc, slots, 1.0, 1.0)
+            ops.decode_attention(q, kc, vc, out, bt, sld, scale, ws)
+
+    def fused():
+        for _ in range(LAYERS):
+            ops.decode_attention(q, kc, vc, out, bt, sld, scale, ws, k_new=kn, v_new=vn, cache_slots=slots)
+
+    def wall_us(fn, reps=50):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    print(f"decode step out of an fp8 cache, {B} requests x {N} cached tokens, {LAYERS} layers, {H}/{Hkv} heads")
+    for name, fn in (("cache write + attention (two launches a layer)", separate), ("attention writes the cache (one launch)", fused)):
+        fn()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fn()
+        w, wg = wall_us(fn), wall_us(graph.replay)
+        print(f"  {name:48s} eager {w:8.1f} us/step ({w / LAYERS:6.1f} per layer)   graph replay {wg:8.1f} us/step "
+              f"({wg / LAYERS:6.1f} per layer)")
+
+
 if __name__ == "__main__":
     # an idle GPU first: its clocks settle after tens of milliseconds of load
     x = torch.randn((4096, 4096), device=dev)
@@ -102,3 +149,5 @@ if __name__ == "__main__":
     run(8, 2048)
     run(1, 2048)
     run(256, 1024)
+    run_fp8_write(8, 2048)
+    run_fp8_write(64, 8192)
