@@ -16,6 +16,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define EXP2FMA4 "v_exp_f32 %3, %3\n v_fma_f32 %4, %4, %9, %4\n v_fma_f32 %5, %5, %9, %5\n v_exp_f32 %6, %6\n v_fma_f32 %7, %7, %9, %7\n v_fma_f32 %8, %8, %9, %8\n"
 #define CHAIN "v_fma_f32 %3, %5, %9, %7\n v_fma_f32 %4, %6, %9, %7\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n v_add_f32 %8, %8, %3\n v_add_f32 %8, %8, %4\n v_cvt_pk_f16_f32 %5, %3, %4\n"
 #define MF "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n"
+// the softmax of one score pair WITHOUT the transcendental unit: exponent = rint via a magic add, fraction through a
+// cubic in packed fp16, 2^n built from the integer part, row sum by a dot product (13 instructions, none of them v_exp)
+#define POLY "v_pk_fma_f32 %[A], %[S], %[M], %[N]\n v_pk_add_f32 %[B], %[A], %[G]\n v_pk_add_f32 %[C], %[B], %[H]\n v_pk_add_f32 %[D], %[A], %[C]\n" \
+             "v_cvt_pk_f16_f32 %[e], %[x0], %[x1]\n v_pk_fma_f16 %[p], %[e], %[x2], %[x3]\n v_pk_fma_f16 %[p], %[p], %[e], %[x4]\n v_pk_fma_f16 %[p], %[p], %[e], %[x5]\n" \
+             "v_perm_b32 %[n], %[x0], %[x1], %[x2]\n v_pk_max_i16 %[n], %[n], %[x3]\n v_pk_lshlrev_b16 %[n], 10, %[n]\n v_pk_mul_f16 %[p], %[p], %[n]\n v_dot2_f32_f16 %[l], %[p], %[x4], %[l]\n"
+#define MFN "v_mfma_f32_32x32x16_bf16 %[acc], %[a], %[b], %[acc]\n"
 #define R16(x) x x x x x x x x x x x x x x x x
 
 template <int MODE>
@@ -40,7 +46,21 @@ __global__ void probe(long long* cycles, float* sink, int iters) {
       asm volatile(R16(CHAIN) : "+v"(acc), "+v"(a), "+v"(b), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5) : "v"(c));
     else if constexpr (MODE == 7)
       asm volatile(R16(EXP2FMA4) : "+v"(acc), "+v"(a), "+v"(b), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5) : "v"(c));
-    else
+    else if constexpr (MODE == 8 || MODE == 9) {
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      static f2 A, B, C, D;  // (values do not matter: throughput only)
+      f2 S = {x0, x1}, M = {c, c}, N = {x2, x3}, G = {x4, x4}, H = {x5, x5};
+      unsigned e = 1, pp = 2, n = 3;
+      float l = 0.f;
+      f2 rA = S, rB = S, rC = S, rD = S;
+      if constexpr (MODE == 8)
+        asm volatile(R16(POLY) : [A] "+v"(rA), [B] "+v"(rB), [C] "+v"(rC), [D] "+v"(rD), [e] "+v"(e), [p] "+v"(pp), [n] "+v"(n), [l] "+v"(l)
+                     : [S] "v"(S), [M] "v"(M), [N] "v"(N), [G] "v"(G), [H] "v"(H), [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [x4] "v"(x4), [x5] "v"(x5));
+      else
+        asm volatile(R16(MFN POLY) : [acc] "+v"(acc), [A] "+v"(rA), [B] "+v"(rB), [C] "+v"(rC), [D] "+v"(rD), [e] "+v"(e), [p] "+v"(pp), [n] "+v"(n), [l] "+v"(l)
+                     : [a] "v"(a), [b] "v"(b), [S] "v"(S), [M] "v"(M), [N] "v"(N), [G] "v"(G), [H] "v"(H), [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [x4] "v"(x4), [x5] "v"(x5));
+      x0 += l + rD[0] + __uint_as_float(pp);
+    } else
       asm volatile(R16(MF FMA6) : "+a"(acc), "+v"(a), "+v"(b), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5) : "v"(c));
   }
   asm volatile("s_nop 15\n s_nop 15" ::: "memory");
@@ -80,6 +100,8 @@ int main() {
     run<4>("16 x (mfma + 2 exp + 4 fma)", threads, iters);
     run<6>("16 x softmax chain of a score pair (7 instr)", threads, iters);
     run<5>("16 x (mfma + softmax chain of a score pair)", threads, iters);
+    run<8>("16 x exp-free chain of a score pair (13 instr)", threads, iters);
+    run<9>("16 x (mfma + exp-free chain of a score pair)", threads, iters);
   }
   return 0;
 }
