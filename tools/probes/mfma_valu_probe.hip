@@ -15,6 +15,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // two exponentials and four fma, independent / the softmax chain of one score pair: fma -> exp -> add -> add -> cvt
 #define EXP2FMA4 "v_exp_f32 %3, %3\n v_fma_f32 %4, %4, %9, %4\n v_fma_f32 %5, %5, %9, %5\n v_exp_f32 %6, %6\n v_fma_f32 %7, %7, %9, %7\n v_fma_f32 %8, %8, %9, %8\n"
 #define CHAIN "v_fma_f32 %3, %5, %9, %7\n v_fma_f32 %4, %6, %9, %7\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n v_add_f32 %8, %8, %3\n v_add_f32 %8, %8, %4\n v_cvt_pk_f16_f32 %5, %3, %4\n"
+#define EXP6_F32 "v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n v_exp_f32 %8, %8\n"
+#define EXP6_F16 "v_exp_f16 %3, %3\n v_exp_f16 %4, %4\n v_exp_f16 %5, %5\n v_exp_f16 %6, %6\n v_exp_f16 %7, %7\n v_exp_f16 %8, %8\n"
 #define MF "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n"
 // the softmax of one score pair WITHOUT the transcendental unit: exponent = rint via a magic add, fraction through a
 // cubic in packed fp16, 2^n built from the integer part, row sum by a dot product (13 instructions, none of them v_exp)
@@ -46,6 +48,14 @@ __global__ void probe(long long* cycles, float* sink, int iters) {
       asm volatile(R16(CHAIN) : "+v"(acc), "+v"(a), "+v"(b), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5) : "v"(c));
     else if constexpr (MODE == 7)
       asm volatile(R16(EXP2FMA4) : "+v"(acc), "+v"(a), "+v"(b), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5) : "v"(c));
+    else if constexpr (MODE == 10)
+      asm volatile(R16(EXP6_F32) : "+v"(acc), "+v"(a), "+v"(b), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5) : "v"(c));
+    else if constexpr (MODE == 11)
+      asm volatile(R16(EXP6_F16) : "+v"(acc), "+v"(a), "+v"(b), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5) : "v"(c));
+    else if constexpr (MODE == 12)
+      asm volatile(R16(MF EXP6_F32) : "+v"(acc), "+v"(a), "+v"(b), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5) : "v"(c));
+    else if constexpr (MODE == 13)
+      asm volatile(R16(MF EXP6_F16) : "+v"(acc), "+v"(a), "+v"(b), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5) : "v"(c));
     else if constexpr (MODE == 8 || MODE == 9) {
       typedef float f2 __attribute__((ext_vector_type(2)));
       static f2 A, B, C, D;  // (values do not matter: throughput only)
@@ -100,6 +110,10 @@ int main() {
     run<4>("16 x (mfma + 2 exp + 4 fma)", threads, iters);
     run<6>("16 x softmax chain of a score pair (7 instr)", threads, iters);
     run<5>("16 x (mfma + softmax chain of a score pair)", threads, iters);
+    run<10>("16 x 6 v_exp_f32", threads, iters);
+    run<11>("16 x 6 v_exp_f16", threads, iters);
+    run<12>("16 x (mfma + 6 v_exp_f32)", threads, iters);
+    run<13>("16 x (mfma + 6 v_exp_f16)", threads, iters);
     run<8>("16 x exp-free chain of a score pair (13 instr)", threads, iters);
     run<9>("16 x (mfma + exp-free chain of a score pair)", threads, iters);
   }
