@@ -155,7 +155,7 @@ struct AttnParams {
   float k_scale, v_scale;     // fp8 K/V cache: value = fp8 x scale
   // In-launch index build (ix_build): workgroup 0 builds the index from `ix`, then stores ix_epoch to *ix_flag
   // (device scope, release); the other work-list workgroups wait for that value before they read anything of the
-  // index.  The band workgroups never read it.
+  // index.  The band workgroups of that form do not read the index (they place a q-block from cu_q instead of qb_meta).
   int ix_build;
   unsigned long long* ix_flag;
   unsigned long long ix_epoch;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_kernel(const AttnParams p
       __syncthreads();  // (the LDS word is free again)
       if (!ok) return;
       // No cache invalidation on this side: nothing of the index has been read by this launch before the epoch is
-      // seen (the band workgroups never read it), and a launch starts with the caches clean of other launches'
+      // seen (the band workgroups of this form do not read it), and a launch starts with the caches clean of other launches'
       // lines -- so no cache on this workgroup's path can hold an older copy of what workgroup 0 wrote.
     }
     __builtin_amdgcn_sched_barrier(0);
