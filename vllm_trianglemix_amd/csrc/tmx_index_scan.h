@@ -39,18 +39,31 @@ __device__ __forceinline__ int wave_inclusive_scan(int x) {
 // Returns the exclusive prefix; `total` receives the workgroup sum.
 template <int NT>
 __device__ __forceinline__ Int4 block_exclusive_scan(Int4 v, Int4* wave_sums /* LDS [NT / 64] */, Int4& total) {
+  static_assert(NT % 64 == 0 && NT / 64 <= 16, "at most 16 waves: their sums are scanned inside one row of 16 lanes");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const Int4 inc{wave_inclusive_scan(v.x), wave_inclusive_scan(v.y), wave_inclusive_scan(v.z), wave_inclusive_scan(v.w)};
   if (lane == 63) wave_sums[wave] = inc;
   __syncthreads();
-  Int4 base{0, 0, 0, 0};
-  Int4 tot{0, 0, 0, 0};
-  for (int w = 0; w < NT / 64; ++w) {
-    if (w < wave) base = base + wave_sums[w];
-    tot = tot + wave_sums[w];
-  }
+  // Every wave scans the waves' sums itself: lane i < NT / 64 holds wave i's sum, four shifts inside the first row of
+  // 16 lanes give the inclusive prefixes, and two lane reads pick this wave's base and the total (one LDS read and a
+  // dozen lane moves where a loop over the 16 sums took 16 LDS reads and 64 additions per thread).
+  Int4 ws{0, 0, 0, 0};
+  if (lane < NT / 64) ws = wave_sums[lane];
+  auto row_scan = [](int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);  // row_shr:8
+    return x;
+  };
+  const Int4 pre{row_scan(ws.x), row_scan(ws.y), row_scan(ws.z), row_scan(ws.w)};  // lane i: sums of waves 0 .. i
+  const int prev = wave > 0 ? wave - 1 : 0;
+  Int4 base{__builtin_amdgcn_readlane(pre.x, prev), __builtin_amdgcn_readlane(pre.y, prev),
+            __builtin_amdgcn_readlane(pre.z, prev), __builtin_amdgcn_readlane(pre.w, prev)};
+  if (wave == 0) base = Int4{0, 0, 0, 0};
+  total = Int4{__builtin_amdgcn_readlane(pre.x, NT / 64 - 1), __builtin_amdgcn_readlane(pre.y, NT / 64 - 1),
+               __builtin_amdgcn_readlane(pre.z, NT / 64 - 1), __builtin_amdgcn_readlane(pre.w, NT / 64 - 1)};
   __syncthreads();
-  total = tot;
   Int4 exc{inc.x - v.x, inc.y - v.y, inc.z - v.z, inc.w - v.w};
   return base + exc;
 }
