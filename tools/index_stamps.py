@@ -19,7 +19,7 @@ for it in range(12):
     torch.cuda.synchronize()
     buf = (ctypes.c_longlong * 16)()
     lib.tmx_index_read_stamps(buf)
-    a = np.array(buf[:10], dtype=np.int64)
-    res.append([a[1] - a[0], a[7] - a[1], a[8] - a[7], a[9] - a[8], a[3] - a[9], a[5] - a[3], a[6] - a[5]])
+    a = np.array(buf[:12], dtype=np.int64)
+    res.append([a[1] - a[0], a[7] - a[1], a[8] - a[7], a[9] - a[8], a[3] - a[9], a[5] - a[3], a[6] - a[5], a[10] - a[9], a[11] - a[10], a[3] - a[11]])
 r = np.median(np.array(res[2:]), axis=0)
-print("cycles: batch+scan1 %d | counts %d | scan2 %d | stores %d | short fill+sync %d | long lists %d | max %d" % tuple(r))
+print("cycles: batch+scan1 %d | counts %d | scan2 %d | stores %d | short fill+sync %d | long lists %d | max %d   (short fill: lists %d, long-list table %d, barrier %d)" % tuple(r))

@@ -323,6 +323,7 @@ __device__ __forceinline__ void index_scan_body(const IndexParams& p, IndexScanS
           fill_qblock(p, qb, kb[k], kr0[k], n, ctx, rq.x + kr0[k], ktr[k], kv[k].x, ke[k].x,
                       first_item_of(run.y, run.z, ke[k].y, ke[k].z, kv[k].y), ke[k].z, 0, 1, kpg[k]);
       }
+      ISTAMP(10);
       if (is_long[k]) {
         const int at = atomicAdd(&sh.num_long, 1);
         if (at < 64) {
@@ -335,6 +336,7 @@ __device__ __forceinline__ void index_scan_body(const IndexParams& p, IndexScanS
         }
       }
     }
+    ISTAMP(11);
     // (a barrier for the LDS table only: the short lists' stores drain while the long lists are written)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     ISTAMP(3);
