@@ -63,6 +63,7 @@ def test_random_steps_match_the_oracle(seed):
     paged = rng.random() < 0.7
     page = int(rng.choice([16, 32, 64]))
     fused = paged and mode != "none" and rng.random() < 0.5  # the launch stores the step's rows itself
+    defer = bool(np.random.default_rng(seed + 77777).random() < 0.5)  # (a stream of its own: the other draws stay as they were)
     fp8 = paged and not fused and D == 128 and rng.random() < 0.35  # an fp8 (e4m3fn) cache read in place
     k_scale, v_scale = ((1.0, 1.0) if rng.random() < 0.5 else (0.75, 1.5)) if fp8 else (1.0, 1.0)
     # chunked prefill: some requests are chunks of a longer prompt (the pattern then refers to the whole prompt)
@@ -88,7 +89,7 @@ def test_random_steps_match_the_oracle(seed):
     out = torch.full((T, H, D), float("nan"), dtype=torch.float32, device=DEV)
     bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
     scale = D ** -0.5
-    desc = dict(seed=seed, q=q_lens, n=seq_lens, heads=(H, Hkv, D), dtype=str(dtype), mode=mode, pat=pat, gate=gate,
+    desc = dict(seed=seed, defer=defer, q=q_lens, n=seq_lens, heads=(H, Hkv, D), dtype=str(dtype), mode=mode, pat=pat, gate=gate,
                 chunk=chunk, paged=paged, page=page, fused=fused, flags=flags, fp8=fp8, scales=(k_scale, v_scale),
                 full_lens=full_lens)
     fl_h = None if full_lens is None else np.asarray(full_lens, np.int32)
@@ -119,9 +120,10 @@ def test_random_steps_match_the_oracle(seed):
             v_new.append(vs[b][ctx:])
         btd = torch.from_numpy(bt).to(DEV)
         resolve = rng.random() < 0.5
+        # (half of the steps hand the attention call an index that is still to be built: TMX_ATTN_BUILD_INDEX)
         idx = ops.build_block_index(cu, sld, cu_h, sl_h, *pat, bm, bn, ops.MODES[mode], chunk_tiles=chunk, tri_min_len=gate,
                                     block_table=btd if resolve else None, page_size=page if resolve else 0,
-                                    full_lens=fl_d, full_lens_cpu=fl_h)
+                                    full_lens=fl_d, full_lens_cpu=fl_h, defer=defer)
         if fused:
             kn, vn = to_dev(np.concatenate(k_new, 0)), to_dev(np.concatenate(v_new, 0))
             slots_d = torch.from_numpy(np.concatenate(new_slots)).to(DEV)
@@ -140,11 +142,12 @@ def test_random_steps_match_the_oracle(seed):
             ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, flags=flags)
     else:
         idx = ops.build_block_index(cu, sld, cu_h, sl_h, *pat, bm, bn, ops.MODES[mode], chunk_tiles=chunk, tri_min_len=gate,
-                                    full_lens=fl_d, full_lens_cpu=fl_h)
+                                    full_lens=fl_d, full_lens_cpu=fl_h, defer=defer)
         cu_k = torch.from_numpy(np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)).to(DEV)
         ops.attention(qd, to_dev(np.concatenate(ks, 0)), to_dev(np.concatenate(vs, 0)), out, idx, cu, sld, scale,
                       cu_seqlens_k=cu_k, flags=flags)
     torch.cuda.synchronize()
+    assert idx.built
     got = out.cpu().numpy()
     ref = orc.varlen_gqa_attention(q, lambda b: k_ref[b], lambda b: v_ref[b], cu_h, seq_lens, scale, mode, *pat,
                                    full_lens=full_lens, tri_min_len=gate)
