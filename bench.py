@@ -530,7 +530,9 @@ def main():
         # dense-causal baselines at the same shape (attention-op level)
         try:
             idx_c = build("causal")
-            work_c = ops.alloc_workspace(idx_c, H, D, dev)
+            # (with the staging area the library sizes for long prompts: K/V rows gathered once per call, V as fp16,
+            # and the kernel's tiles then come into LDS by LDS-DMA; the gather is inside the timed call)
+            work_c = ops.alloc_workspace(idx_c, H, D, dev, num_kv_heads=Hkv)
 
             def dense_own():
                 ops.attention(inp["q"], kc, vc, out, idx_c, inp["cu"], inp["sl"], scale,
@@ -549,6 +551,7 @@ def main():
                              "dense_causal_frac_of_peak": fl_dense / (t_dense * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                              "triangle_TFLOPs": fl_tri / (t_attn_ms * 1e-3) / 1e12,
                              "triangle_frac_of_peak": fl_tri / (t_attn_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS}
+            extra["mfma"]["dense_causal_form"] = "staged (LDS-DMA tiles)" if len(work_c) > 2 else "register"
             extra["speedup_vs_own_dense"] = t_dense / (ms_per_step)
             # attention of the whole model with the reference's preset for this size (trianglemix_config.py:65-72:
             # 8 triangle layers for an 8B model, 12 for 32B; the other layers attend causally above 2048 tokens)

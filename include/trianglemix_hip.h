@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TMX_ABI_VERSION 5
+#define TMX_ABI_VERSION 6
 /* int32 entries of tmx_index_t.scratch for a batch of `batch` requests and a capacity of R q-blocks */
 #define TMX_INDEX_SCRATCH_INTS(batch, R) ((batch) + 1 + 2 * ((R) + 1) + 8 * ((R) / 1024 + 1))
 
@@ -279,7 +279,26 @@ typedef struct tmx_attention_args_t {
    * fetch the K/V tiles. */
   uint32_t flags;
   uint32_t reserved;
+
+  /* Optional staging area of the dense causal kernel (device; NULL: not used), kv_stage_rows rows:
+   * [2][kv_stage_rows][num_kv_heads][128] 16-bit values.  A causal launch (TMX_MODE_CAUSAL, head size 128) first
+   * gathers the key and value rows of its long requests into it -- out of the pages, the step's own rows or an fp8
+   * cache, converted once -- and its tiles then reach LDS by LDS-DMA: same results, about 7 % less time at 32k
+   * tokens.  kv_stage_rows must be at least tmx_dense_stage_rows() of the batch (a smaller area is never written
+   * past its end: the requests' rows are then left unwritten).  Contents are scratch: nothing is kept between
+   * calls, and calls that share an area must not overlap. */
+  void* kv_stage;
+  int64_t kv_stage_rows;
 } tmx_attention_args_t;
+
+/* Rows of the staging area (tmx_attention_args_t.kv_stage) for a batch, from the host copies of cu_seqlens_q /
+ * seq_lens: the sequence lengths of the requests the dense causal kernel takes (17 query rows or more), each
+ * rounded up to a multiple of 64 -- or 0 when the gather would not pay (it copies every key row once; the kernel
+ * reads every key row once per 64 query rows): fewer than min_rows_per_request query rows per such request on
+ * average (negative: the default, 4096; 0: always).  No counterpart in the reference, whose dense layers run
+ * torch's eager product (vllm/attention/ascend_trianglemix.py:88-106). */
+int64_t tmx_dense_stage_rows(const int32_t* cu_seqlens_q_host, const int32_t* seq_lens_host, int batch,
+                             int min_rows_per_request);
 
 #define TMX_ATTN_SKIP_COMBINE 1u
 #define TMX_ATTN_ONLY_COMBINE 2u

@@ -262,8 +262,9 @@ def _to_dev(x, dtype):
 
 def _run_varlen(ops, q, k_list, v_list, q_lens, seq_lens, scale, mode, pattern, dtype=torch.bfloat16,
                 out_dtype=torch.float32, paged=False, page_size=16, bias=None, chunk=64, gate=0, q_pad=0,
-                resolve_pages=True, full_lens=None, flags=0):
-    """q: [T, H, D] float32 (already rounded); k_list/v_list: per-request [seq_len, Hkv, D]."""
+                resolve_pages=True, full_lens=None, flags=0, stage=False):
+    """q: [T, H, D] float32 (already rounded); k_list/v_list: per-request [seq_len, Hkv, D].
+    stage: a causal launch gets a staging area (poisoned with NaN) whatever the requests' lengths."""
     T, H, D = q.shape
     Hkv = k_list[0].shape[1]
     si, sl, last = pattern
@@ -311,14 +312,27 @@ def _run_varlen(ops, q, k_list, v_list, q_lens, seq_lens, scale, mode, pattern, 
                     t0 = int(col[e]) * 32
                     assert tp[e, 0] == bt[b_, t0 // page_size]
                     assert tp[e, 1] == bt[b_, min(t0 + 16, seq_lens[b_] - 1) // page_size]
-        ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, bias=bias, flags=flags)
+        ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, bias=bias, flags=flags,
+                      kv_stage=_stage_for(ops, idx, q_lens, seq_lens, Hkv) if stage else None)
     else:
         kd = _to_dev(np.concatenate(k_list, 0), dtype)
         vd = _to_dev(np.concatenate(v_list, 0), dtype)
         cu_k = torch.from_numpy(np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)).to(DEV)
-        ops.attention(qd, kd, vd, out, idx, cu, sld, scale, cu_seqlens_k=cu_k, bias=bias, flags=flags)
+        ops.attention(qd, kd, vd, out, idx, cu, sld, scale, cu_seqlens_k=cu_k, bias=bias, flags=flags,
+                      kv_stage=_stage_for(ops, idx, q_lens, seq_lens, Hkv) if stage else None)
     torch.cuda.synchronize()
     return out.float().cpu().numpy()
+
+
+def _stage_for(ops, idx, q_lens, seq_lens, Hkv, extra_rows=0):
+    """A staging area for the batch whatever its lengths (the library's default stages long prompts only), full of
+    NaN: every row the kernel reads must have been written by the gather of the same call."""
+    cu_h = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    idx.stage_rows = ops.dense_stage_rows(cu_h, np.asarray(seq_lens, np.int32), 0)
+    st = ops.alloc_kv_stage(idx.stage_rows + extra_rows, Hkv, DEV)
+    if st is not None:
+        st.fill_(float("nan"))
+    return st
 
 
 def _rand_case(seed, q_lens, seq_lens, H, Hkv, D):
@@ -609,6 +623,10 @@ def test_attention_properties_at_full_size(n, paged, H, Hkv, cache, mode):
     idx = ops.build_block_index(cu, sld, cu_h, sl_h, *pat, ops.attention_block_m(H, Hkv), 32, ops.MODES[mode],
                                 chunk_tiles=32 if mode == "triangle" else 64,
                                 block_table=bt if in_kernel_pages else None, page_size=page if in_kernel_pages else 0)
+    # work areas of the calls below; a causal launch of this length gets the dense kernel's staging area (the library's
+    # own rule) and runs the staged form: K/V rows gathered first, tiles by LDS-DMA
+    ws = ops.alloc_workspace(idx, H, D, DEV, num_kv_heads=Hkv)
+    assert len(ws) == (3 if mode == "causal" and cache != "fp8-gather" else 2)
     outs = []
     seen_k = seen_v = None
     if fp8:
@@ -620,7 +638,7 @@ def test_attention_properties_at_full_size(n, paged, H, Hkv, cache, mode):
             o = torch.full((n, H, D), float("nan"), dtype=torch.float32, device=DEV)
             if in_place:
                 ops.attention(q, kc.view(torch.float8_e4m3fn), vc.view(torch.float8_e4m3fn), o, idx, cu, sld, D ** -0.5,
-                              block_table=bt, k_scale=k_scale, v_scale=vs_)
+                              block_table=bt, k_scale=k_scale, v_scale=vs_, workspace=ws)
                 return o, None
             rows = ops.gather_dequant_kv_fp8(kc, vc, bt, sld, cu, n, n, torch.bfloat16, k_scale, vs_)
             ops.attention(q, rows[0], rows[1], o, idx, cu, sld, D ** -0.5, cu_seqlens_k=cu)
@@ -632,6 +650,12 @@ def test_attention_properties_at_full_size(n, paged, H, Hkv, cache, mode):
         for vs_ in (v_scale, 2 * v_scale):
             outs.append(attend(vs_)[0])
         assert torch.equal(outs[1], 2 * outs[0])
+        if len(ws) == 3:
+            # the register form of the dense kernel (no staging area): the same bits
+            o = torch.full((n, H, D), float("nan"), dtype=torch.float32, device=DEV)
+            ops.attention(q, kc.view(torch.float8_e4m3fn), vc.view(torch.float8_e4m3fn), o, idx, cu, sld, D ** -0.5,
+                          block_table=bt, k_scale=k_scale, v_scale=v_scale, workspace=ws[:2])
+            assert torch.equal(o, outs[0])
         ops.reshape_and_cache_fp8(k, torch.ones_like(v1), kc, vc, slots, k_scale, 1.0)
         o, _ = attend(1.0)
         assert (o - 1.0).abs().max().item() < (5e-4 if mode == "causal" else 1e-5)
@@ -648,9 +672,14 @@ def test_attention_properties_at_full_size(n, paged, H, Hkv, cache, mode):
                 kc = torch.zeros((n // page, page, Hkv, D), dtype=torch.bfloat16, device=DEV)
                 vc = torch.zeros_like(kc)
                 ops.reshape_and_cache(k, v, kc, vc, slots)
-                ops.attention(q, kc, vc, o, idx, cu, sld, D ** -0.5, block_table=bt)
+                ops.attention(q, kc, vc, o, idx, cu, sld, D ** -0.5, block_table=bt, workspace=ws)
+                if len(ws) == 3 and not outs:
+                    # the register form of the dense kernel (no staging area): the same bits
+                    o2 = torch.full_like(o, float("nan"))
+                    ops.attention(q, kc, vc, o2, idx, cu, sld, D ** -0.5, block_table=bt, workspace=ws[:2])
+                    assert torch.equal(o2, o)
             else:
-                ops.attention(q, k, v, o, idx, cu, sld, D ** -0.5, cu_seqlens_k=cu)
+                ops.attention(q, k, v, o, idx, cu, sld, D ** -0.5, cu_seqlens_k=cu, workspace=ws)
             outs.append(o)
         lin = (outs[0] + outs[1] - outs[2]).abs().max().item()
         assert lin < 0.05  # v1 + v2 is re-rounded to bf16: 2^-8 relative on values up to ~8
@@ -1465,6 +1494,60 @@ def test_dense_causal_kernel_matches_oracle_and_work_list(case):
     o16 = out_dtype != torch.float32
     assert_close(got, ref, f"dense causal kernel, {str(dtype)[6:]}", out16=o16)
     assert_close(plain, ref, f"work list (causal launch), {str(dtype)[6:]}", out16=o16)
+    # the staged form (K/V rows gathered first, tiles by LDS-DMA) puts the same values into LDS: the same bits out
+    staged = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, "causal", (0, 0, 0), stage=True, **kw)
+    assert np.array_equal(staged, got), np.abs(staged - got).max()
+
+
+@pytest.mark.parametrize("binding", ["torch", "ctypes"])
+def test_dense_causal_staging_area(monkeypatch, binding):
+    """The staging area of the dense causal kernel through both bindings: sized by dense_stage_rows (long prompts
+    only by default; every request with 17 query rows or more when asked), handed over as kv_stage or as the third
+    member of the workspace, larger than needed or exactly as needed; an area that is too small is refused; a
+    batch whose index says "no staging" ignores the area.  Ragged batch with context, a request below 17 rows and
+    a decode row between the staged ones."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "_BINDING", binding)
+    H, Hkv, D = 8, 2, 128
+    q_lens, seq_lens = [300, 64, 17, 5, 129, 1, 70], [300, 500, 67, 900, 129, 70, 2111]
+    cu_h = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    sl_h = np.asarray(seq_lens, np.int32)
+    assert ops.dense_stage_rows(cu_h, sl_h) == 0                       # short requests: staging would not pay
+    assert ops.dense_stage_rows(cu_h, sl_h, 0) == 320 + 512 + 128 + 192 + 2112
+    assert ops.dense_stage_rows([0, 4096], [4096]) == 4096 and ops.dense_stage_rows([0, 4095], [4095]) == 0
+    assert ops.dense_stage_rows([0, 4096, 4097], [5000, 77]) == 5056   # the decode row is not the kernel's
+    q, ks, vs = _rand_case(99, q_lens, seq_lens, H, Hkv, D)
+    scale = D ** -0.5
+    kw = dict(paged=True, page_size=16, chunk=16)
+    plain = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, "causal", (0, 0, 0), **kw)
+    staged = _run_varlen(ops, q, ks, vs, q_lens, seq_lens, scale, "causal", (0, 0, 0), stage=True, **kw)
+    assert np.array_equal(staged, plain)
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu_h, seq_lens, scale, "causal", 0, 0, 0)
+    assert_close(staged, ref, "dense causal kernel, staged form")
+    # contiguous K/V, the area as a member of the workspace, and more rows than needed
+    bm = ops.attention_block_m(H, Hkv)
+    idx, cu, sld = _build(ops, q_lens, seq_lens, 0, 0, 0, bm, 32, ops.MODES["causal"], 16, 0)
+    assert idx.stage_rows == 0 and len(ops.alloc_workspace(idx, H, D, DEV, num_kv_heads=Hkv)) == 2
+    idx.stage_rows = ops.dense_stage_rows(cu_h, sl_h, 0)
+    ws = ops.alloc_workspace(idx, H, D, DEV, num_kv_heads=Hkv)
+    assert len(ws) == 3 and tuple(ws[2].shape) == (2, idx.stage_rows, Hkv, 128)
+    qd = _to_dev(q, torch.bfloat16)
+    kd, vd = _to_dev(np.concatenate(ks, 0), torch.bfloat16), _to_dev(np.concatenate(vs, 0), torch.bfloat16)
+    cu_k = torch.from_numpy(np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)).to(DEV)
+    outs = []
+    for work in (ws, ws[:2] + (ops.alloc_kv_stage(idx.stage_rows + 100, Hkv, DEV),), ws[:2]):
+        out = torch.full((int(cu_h[-1]), H, D), float("nan"), dtype=torch.float32, device=DEV)
+        ops.attention(qd, kd, vd, out, idx, cu, sld, scale, cu_seqlens_k=cu_k, workspace=work)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+    assert_close(outs[0].cpu().numpy(), ref, "dense causal kernel, staged form, contiguous K/V")
+    with pytest.raises(RuntimeError):
+        ops.attention(qd, kd, vd, out, idx, cu, sld, scale, cu_seqlens_k=cu_k,
+                      kv_stage=ops.alloc_kv_stage(idx.stage_rows - 64, Hkv, DEV))
+    with pytest.raises(RuntimeError):
+        ops.attention(qd, kd, vd, out, idx, cu, sld, scale, cu_seqlens_k=cu_k,
+                      kv_stage=ops.alloc_kv_stage(idx.stage_rows, Hkv + 1, DEV))
 
 
 @pytest.mark.parametrize("case", [
@@ -1885,6 +1968,14 @@ def test_fp8_cache_read_in_place(dtype, page, heads):
             ref = orc.varlen_gqa_attention(q, lambda b: kd[b], lambda b: vd[b], cu_h, seq_lens, scale, mode, *pat,
                                            tri_min_len=2048 if mode == "triangle" else 0)
             got = out.cpu().numpy()
+            if mode == "causal":
+                # staged form of the dense kernel: the gather descales the fp8 rows (same rounding): the same bits
+                out_s = torch.full_like(out, float("nan"))
+                ops.attention(_to_dev(q, dtype), kc.view(torch.float8_e4m3fn), vc.view(torch.float8_e4m3fn), out_s, idx, cu,
+                              sld, scale, block_table=btd, flags=flags, k_scale=k_scale, v_scale=v_scale,
+                              kv_stage=_stage_for(ops, idx, q_lens, seq_lens, Hkv))
+                assert torch.equal(out_s, out)
+                idx.stage_rows = 0
             name = f"fp8 cache read in place, {H}/{Hkv} heads, {str(dtype)[6:]}"
             assert_close(got, ref, f"{name}: {'band + work list + decode' if mode == 'triangle' else 'dense causal + decode'}",
                          info=(mode, resolve))
@@ -1963,6 +2054,17 @@ def test_two_sources_equal_cache_only_and_backend_overlaps_every_step(monkeypatc
         assert torch.equal(got, want), (mode, (got - want).abs().max().item())
         ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu, seq_lens, scale, mode, *pat, tri_min_len=gate)
         assert_close(got.cpu().numpy(), ref, "two sources (k_new / v_new)")
+        if mode == "causal":
+            # staged form of the dense kernel: its gather reads both sources and makes the step's cache write
+            cache = part.clone()
+            got_s = torch.full_like(want, float("nan"))
+            ops.attention(qd, cache[0], cache[1], got_s, idx, cud, sld, scale, block_table=btd, k_new=kn, v_new=vn,
+                          cache_slots=torch.from_numpy(slots).to(DEV), kv_stage=_stage_for(ops, idx, q_lens, seq_lens, Hkv))
+            torch.cuda.synchronize()
+            assert torch.equal(got_s, want)
+            sl_t = torch.from_numpy(slots).to(DEV)
+            assert torch.equal(cache.view(2, nblk * page, Hkv, D)[:, sl_t], full.view(2, nblk * page, Hkv, D)[:, sl_t])
+            idx.stage_rows = 0
     # through the backend, write beside the attention against write first
     results = []
     for write_mode in ("serial", "stream", "fused"):

@@ -420,3 +420,18 @@ def test_index_sizes_run_lengths_on_long_requests():
         want = (len(rp) - 1, len(ci), len(items), int(part_ptr[-1]), int(np.count_nonzero(np.diff(part_ptr))),
                 int(np.max(np.diff(rp))))
         assert got == want, (case, bm, seq, qlen, si, sl, last, chunk, full)
+
+
+def test_dense_stage_rows_host_rule():
+    """Rows of the dense causal kernel's staging area: the sequence lengths of the requests with 17 query rows or
+    more, each rounded up to 64; 0 when those requests average fewer query rows than the threshold (default 4096)."""
+    assert ops.dense_stage_rows([0, 4096], [4096]) == 4096
+    assert ops.dense_stage_rows([0, 4095], [4095]) == 0
+    assert ops.dense_stage_rows([0, 4095], [4095], 0) == 4096
+    assert ops.dense_stage_rows([0, 2048], [100000], 2048) == 100032            # a chunk behind a long context
+    assert ops.dense_stage_rows([0, 8192, 8193, 8209], [8192, 500, 16]) == 8192  # decode row and a 16-row request: not staged
+    assert ops.dense_stage_rows([0, 8192, 8209], [8192, 17]) == 8192 + 64        # 17 rows: the kernel's, average still 4104
+    assert ops.dense_stage_rows([0, 8192, 8209, 8226], [8192, 17, 17]) == 0      # average below the threshold
+    assert ops.dense_stage_rows([0], []) == 0
+    with pytest.raises(RuntimeError):
+        ops.dense_stage_rows([0, 5], [5, 6])

@@ -1,5 +1,6 @@
 """Times the dense causal kernel alone (one prompt, paged 16-bit cache, Qwen3-8B heads) and checks it against torch's
-fp32 SDPA on a few rows.  usage (GPU box): TRIANGLEMIX_BINDING=ctypes TMX_LIB_PATH=... python tools/dense_bench.py [n]"""
+fp32 SDPA on a few rows.  usage (GPU box): TRIANGLEMIX_BINDING=ctypes TMX_LIB_PATH=... python tools/dense_bench.py [n]
+TMX_DENSE_STAGE=0: without the staging area (the register form of the tile fetch); 2: staged at any length."""
 import os
 import sys
 
@@ -19,7 +20,10 @@ bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
 chunk = ops.suggest_chunk_tiles(inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn, ops.MODES["causal"], ops.units_per_item(H, Hkv))
 idx = ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn, ops.MODES["causal"],
                             chunk_tiles=chunk, block_table=inp["block_table"], page_size=bench.PAGE)
-work = ops.alloc_workspace(idx, H, D, dev)
+staged = os.environ.get("TMX_DENSE_STAGE", "1") != "0"
+if os.environ.get("TMX_DENSE_STAGE") == "2":  # staged whatever the length (the library's default: from 4096 rows on)
+    idx.stage_rows = ops.dense_stage_rows(inp["cu_h"], inp["sl_h"], 0)
+work = ops.alloc_workspace(idx, H, D, dev, num_kv_heads=Hkv if staged else None)
 out = torch.empty_like(inp["q"])
 kc, vc = inp["kv_cache"][0], inp["kv_cache"][1]
 
@@ -44,9 +48,9 @@ bt = inp["block_table"][0].long()
 k = kc[bt].reshape(-1, Hkv, D)[:n].float()
 v = vc[bt].reshape(-1, Hkv, D)[:n].float()
 err = 0.0
-for row in (0, 1, 63, 64, 2047, n // 2 + 17, n - 65, n - 1):
+for row in (0, 1, 63, 64, min(2047, n - 1), n // 2 + 17, n - 65, n - 1):
     q = inp["q"][row].float().view(Hkv, H // Hkv, D)
     sc = torch.einsum("kgd,nkd->kgn", q, k[: row + 1]) * D ** -0.5
     ref = torch.einsum("kgn,nkd->kgd", torch.softmax(sc, -1), v[: row + 1]).reshape(H, D)
     err = max(err, float((out[row].float() - ref).abs().max()))
-print(f"dense causal n={n}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s  max err on sampled rows {err:.2e}", flush=True)
+print(f"dense causal n={n} ({'staged' if len(work) > 2 else 'register'} form): {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s  max err on sampled rows {err:.2e}", flush=True)

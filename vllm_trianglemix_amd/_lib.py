@@ -14,7 +14,7 @@ TMX_OK, TMX_ERR_INVALID_ARG, TMX_ERR_UNSUPPORTED, TMX_ERR_HIP, TMX_ERR_CAPACITY 
 TMX_F32, TMX_BF16, TMX_F16, TMX_FP8_E4M3 = range(4)
 TMX_MODE_NONE, TMX_MODE_CAUSAL, TMX_MODE_TRIANGLE = range(3)
 TMX_MASK_STREAMING, TMX_MASK_LAST, TMX_MASK_MIDDLE, TMX_MASK_TRIANGLE, TMX_MASK_DENSE = range(5)
-TMX_ABI_VERSION = 5
+TMX_ABI_VERSION = 6
 
 # every symbol include/trianglemix_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "tmx_replace_neg_inf", "tmx_index_sizes", "tmx_build_block_index", "tmx_attention", "tmx_reshape_and_cache",
     "tmx_reshape_and_cache_fp8", "tmx_gather_dequant_kv_fp8", "tmx_suggest_chunk_tiles",
     "tmx_attention_static_ws", "tmx_static_workspace_bytes", "tmx_static_workspace_warmup", "tmx_eager_attention_f32",
-    "tmx_decode_attention", "tmx_decode_workspace_rows",
+    "tmx_decode_attention", "tmx_decode_workspace_rows", "tmx_dense_stage_rows",
 )
 
 
@@ -72,6 +72,7 @@ class AttentionArgs(Structure):
         ("nnz_tiles", c_int64),
         ("partial_o", c_void_p), ("partial_ml", c_void_p),
         ("flags", c_uint32), ("reserved", c_uint32),
+        ("kv_stage", c_void_p), ("kv_stage_rows", c_int64),
     ]
 
 class DecodeArgs(Structure):
@@ -132,6 +133,8 @@ def load() -> ctypes.CDLL:
     lib.tmx_decode_attention.argtypes = [POINTER(DecodeArgs), c_void_p]
     lib.tmx_decode_workspace_rows.argtypes = [c_int, c_int, c_int, c_int, c_int]
     lib.tmx_decode_workspace_rows.restype = c_int64
+    lib.tmx_dense_stage_rows.argtypes = [c_void_p, c_void_p, c_int, c_int]
+    lib.tmx_dense_stage_rows.restype = c_int64
     lib.tmx_reshape_and_cache.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                           c_int64, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p]

@@ -173,11 +173,15 @@ class TriangleMixAttentionMetadata:
             self.__dict__["_fp8_rows"] = hit
         return hit
 
-    def workspace(self, idx: "ops.BlockIndex", num_heads: int, head_size: int, device) -> tuple:
-        key = (id(idx), num_heads, head_size)
+    def workspace(self, idx: "ops.BlockIndex", num_heads: int, head_size: int, device,
+                  num_kv_heads: Optional[int] = None) -> tuple:
+        """Work areas of the step's attention calls with `idx`, made once and shared by the layers (they run one
+        after the other): the partial results of split q-blocks and, for the causal index of a step with long
+        prompts, the staging area of the dense causal kernel."""
+        key = (id(idx), num_heads, head_size, num_kv_heads)
         ws = self._workspaces.get(key)
         if ws is None:
-            ws = ops.alloc_workspace(idx, num_heads, head_size, device)
+            ws = ops.alloc_workspace(idx, num_heads, head_size, device, num_kv_heads=num_kv_heads)
             self._workspaces[key] = ws
         return ws
 
@@ -419,7 +423,7 @@ class TriangleMixAttentionImpl(_ImplBase):
         pattern = self.pattern if self.use_triangle else (0, 0, 0)
         tri_min_len = self.tri_min_len if self.use_triangle else 0
         idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len)
-        ws = m.workspace(idx, self.num_heads, self.head_size, q.device)
+        ws = m.workspace(idx, self.num_heads, self.head_size, q.device, self.num_kv_heads)
         k_rows = v_rows = None
         if writes_cache and n_tok > 0:
             k_rows = key[:n_tok].view(n_tok, self.num_kv_heads, self.head_size)
@@ -509,7 +513,7 @@ class TriangleMixAttentionImpl(_ImplBase):
         pattern = self.pattern if self.use_triangle else (0, 0, 0)
         tri_min_len = self.tri_min_len if self.use_triangle else 0
         idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len, fp8_cache=self.head_size == 128)
-        ws = m.workspace(idx, self.num_heads, self.head_size, q.device)
+        ws = m.workspace(idx, self.num_heads, self.head_size, q.device, self.num_kv_heads)
         if self.head_size == 128:
             # the attention kernel reads the fp8 pages in place and descales inside its tile loop
             ops.attention(q, key_cache, value_cache, out, idx, m.query_start_loc, m.seq_lens, self.scale,

@@ -36,8 +36,20 @@ struct DenseParams {
   float scale_log2;
   int kv_fp8;               // K/V are an fp8 (e4m3fn) paged cache: strides in bytes, value = fp8 x scale
   float k_scale, v_scale;
+  // Staging area, or NULL: [2][stage_rows][Hkv][128] 16-bit values.  A pass ahead of the kernel gathers the K rows
+  // (first half) and the V rows (second half, as fp16) of the requests the kernel takes into it, request after
+  // request, each padded to a multiple of 64 rows; the kernel's tiles then come into LDS by LDS-DMA.
+  void* stage;
+  long long stage_rows;
 };
 
 int launch_dense_causal(const DenseParams& p, bool bf16, bool paged, hipStream_t s);
+
+// Rows of the staging area for a batch: the sequence lengths of the requests with at least kDenseMinRows query
+// rows, each rounded up to a multiple of 64 -- or 0 when staging does not pay: it copies every key row once, the
+// kernel reads every key row once per 64 query rows, so it pays from a few thousand query rows per request on
+// (`min_rows_per_request` on average; negative: the default).
+constexpr int kDenseStageMinRows = 4096;
+long long dense_stage_rows(const int32_t* cu_q_host, const int32_t* seq_lens_host, int batch, int min_rows_per_request);
 
 }  // namespace tmx

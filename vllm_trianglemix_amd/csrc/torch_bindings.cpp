@@ -141,7 +141,7 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
                int64_t num_partials, int64_t num_split_qblocks, const std::optional<Tensor>& full_lens,
                int64_t flags, int64_t nnz_tiles, const std::optional<Tensor>& k_new, const std::optional<Tensor>& v_new,
                const std::optional<Tensor>& cache_slots, double k_scale, double v_scale, int64_t index_block_m,
-               int64_t index_block_n) {
+               int64_t index_block_n, const std::optional<Tensor>& kv_stage) {
   TORCH_CHECK(query.is_cuda(), "trianglemix: query must be on a HIP device (there is no CPU path)");
   const DeviceGuard guard(query.device());
   TORCH_CHECK(query.dim() == 3 && out.dim() == 3 && query.sizes() == out.sizes(), "trianglemix: query / out must both be [T, H, D]");
@@ -277,6 +277,15 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
   a.partial_o = partial_o.has_value() ? partial_o->data_ptr<float>() : nullptr;
   a.partial_ml = partial_ml.has_value() ? partial_ml->data_ptr<float>() : nullptr;
   a.flags = (uint32_t)flags;
+  if (kv_stage.has_value()) {
+    // staging area of the dense causal kernel: [2][rows][Hkv][128] 16-bit values
+    on_gpu(*kv_stage, query, "kv_stage");
+    TORCH_CHECK(kv_stage->dim() == 4 && kv_stage->size(0) == 2 && kv_stage->size(2) == hkv && kv_stage->size(3) == 128 &&
+                    kv_stage->element_size() == 2 && kv_stage->is_contiguous(),
+                "trianglemix: kv_stage must be a contiguous 16-bit [2, rows, Hkv, 128] tensor");
+    a.kv_stage = kv_stage->data_ptr();
+    a.kv_stage_rows = kv_stage->size(1);
+  }
   check(tmx_attention(&a, stream_of(query)));
 }
 
@@ -432,7 +441,8 @@ TORCH_LIBRARY(_trianglemix_C, m) {
         "Tensor? partial_o, Tensor? partial_ml, Tensor? bias, float scale, int si, int sl, int last, int mode, "
         "int tri_min_len, int chunk_tiles, int num_items, int num_partials, int num_split_qblocks, "
         "Tensor? full_lens=None, int flags=0, int nnz_tiles=0, Tensor? k_new=None, Tensor? v_new=None, "
-        "Tensor? cache_slots=None, float k_scale=1.0, float v_scale=1.0, int index_block_m=0, int index_block_n=0) -> ()");
+        "Tensor? cache_slots=None, float k_scale=1.0, float v_scale=1.0, int index_block_m=0, int index_block_n=0, "
+        "Tensor? kv_stage=None) -> ()");
   m.impl("trianglemix_attention", c10::DispatchKey::CUDA, &attention);
   m.def("trianglemix_decode_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, Tensor block_table, "
         "Tensor seq_lens, Tensor! partial_o, Tensor! partial_ml, float scale, Tensor? k_new=None, Tensor? v_new=None, "

@@ -155,7 +155,7 @@ class BlockIndex:
     allocation and one launch sequence."""
     __slots__ = ("buf", "_off", "sizes", "c", "batch", "block_m", "block_n", "mode", "si", "sl", "last",
                  "chunk_tiles", "tri_min_len", "block_table", "full_lens", "full_lens_cpu", "_op_args", "built",
-                 "_batch_tensors")
+                 "_batch_tensors", "stage_rows")
 
     def __init__(self, buf, off, sizes, c, batch, block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
                  block_table, full_lens, full_lens_cpu):
@@ -169,6 +169,8 @@ class BlockIndex:
         # the first attention call with the index builds it (TMX_ATTN_BUILD_INDEX), or build_now()
         self.built = True
         self._batch_tensors = None
+        # rows of the dense causal kernel's staging area for this batch (0: none is used): dense_stage_rows()
+        self.stage_rows = 0
 
     def build_now(self) -> None:
         """Builds a deferred index with a launch of its own (what the first attention call would otherwise do)."""
@@ -298,6 +300,8 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
     c.full_lens_host = None if fl_h is None else _np_ptr(fl_h)
     idx = BlockIndex(buf, off, sz, c, batch, block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
                      block_table, full_lens, fl_h)
+    if mode == MODES["causal"]:
+        idx.stage_rows = dense_stage_rows(cu_h, sl_h)
     if defer:
         idx.built = False
         idx._batch_tensors = (cu_seqlens_q, seq_lens)
@@ -307,6 +311,24 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
                                                 _np_ptr(cu_h),
                                                 _np_ptr(sl_h), _stream(dev)))
     return idx
+
+
+def dense_stage_rows(cu_seqlens_q_cpu, seq_lens_cpu, min_rows_per_request: int = -1) -> int:
+    """Rows of the dense causal kernel's staging area for a batch (``tmx_dense_stage_rows``): the sequence lengths of
+    its long requests, each rounded up to 64 -- or 0 where staging would not pay (fewer than
+    ``min_rows_per_request`` query rows per such request on average; negative: the library's default; 0: always)."""
+    cu = np.ascontiguousarray(np.asarray(cu_seqlens_q_cpu), dtype=np.int32)
+    sl_ = np.ascontiguousarray(np.asarray(seq_lens_cpu), dtype=np.int32)
+    if cu.shape[0] != sl_.shape[0] + 1:
+        raise RuntimeError("cu_seqlens_q must have one entry more than seq_lens")
+    return int(_lib.load().tmx_dense_stage_rows(_np_ptr(cu), _np_ptr(sl_), int(sl_.shape[0]), int(min_rows_per_request)))
+
+
+def alloc_kv_stage(rows: int, num_kv_heads: int, device) -> Optional[torch.Tensor]:
+    """The staging area for ``rows`` key rows: ``[2, rows, Hkv, 128]`` 16-bit values (``None`` for 0 rows)."""
+    if rows <= 0:
+        return None
+    return torch.empty((2, int(rows), int(num_kv_heads), 128), dtype=torch.float16, device=device)
 
 
 # --------------------------------------------------------------------------- attention
@@ -345,6 +367,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
               cu_seqlens_k: Optional[torch.Tensor] = None, block_table: Optional[torch.Tensor] = None,
               bias: Optional[torch.Tensor] = None, workspace: Optional[Sequence[torch.Tensor]] = None,
               flags: int = 0, static_workspace: bool = False, k_scale: float = 1.0, v_scale: float = 1.0,
+              kv_stage: Optional[torch.Tensor] = None,
               k_new: Optional[torch.Tensor] = None, v_new: Optional[torch.Tensor] = None,
               cache_slots: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Masked attention over the tiles ``index`` lists.
@@ -357,6 +380,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     An fp8 (e4m3fn) paged cache (``k``/``v`` of dtype uint8 or float8_e4m3fn, as ``reshape_and_cache_fp8`` writes
     it) is read in place: the kernel descales inside its tile loop with ``k_scale`` / ``v_scale`` (head size 128).
 
+    ``kv_stage`` (or a third member of ``workspace``, as :func:`alloc_workspace` makes it): the staging area of
+    the dense causal kernel, :func:`alloc_kv_stage` of at least ``index.stage_rows`` rows.  A causal launch whose
+    index says that staging pays (``index.stage_rows > 0``) gathers its K/V rows into it first and streams its
+    tiles from there: same results, less time on long prompts.
+
     ``static_workspace``: call ``tmx_attention_static_ws`` -- the partial results of split q-blocks go
     to the library's fixed device array instead of ``workspace`` (nothing is allocated; steps that need
     more than ``tmx_static_workspace_bytes()`` raise).
@@ -367,6 +395,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     ``bias``: optional additive ``[rows >= max position + 1, cols >= max seq_len]``, or 4-D
     ``[1|batch, 1|heads, rows, cols]`` (per request and / or per head).
     """
+    if workspace is not None and len(workspace) > 2:
+        kv_stage = workspace[2] if kv_stage is None else kv_stage
+        workspace = workspace[:2]
+    if kv_stage is not None:
+        if index.stage_rows <= 0:
+            kv_stage = None  # (this batch does not stage)
+        elif (kv_stage.dim() != 4 or kv_stage.shape[0] != 2 or kv_stage.shape[3] != 128 or kv_stage.element_size() != 2
+              or not kv_stage.is_contiguous() or kv_stage.shape[1] < index.stage_rows or kv_stage.device != q.device
+              or kv_stage.shape[2] != (k.shape[2] if k.dim() == 4 else k.shape[1])):
+            raise RuntimeError("kv_stage must be a contiguous 16-bit [2, rows >= index.stage_rows, Hkv, 128] tensor on "
+                               "the device of q (ops.alloc_kv_stage)")
     C = None if static_workspace else _op_binding()
     if C is not None:
         # the registered operator (csrc/torch_bindings.cpp): the same library call, argument checks in C++,
@@ -391,7 +430,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
                                     tile_pages, part_o, part_ml, bias, float(scale),
                                     index.si, index.sl, index.last, index.mode, index.tri_min_len, index.chunk_tiles,
                                     n_items, n_part, n_split, index.full_lens, int(flags), nnz, k_new, v_new, cache_slots,
-                                    float(k_scale), float(v_scale), index.block_m, index.block_n)
+                                    float(k_scale), float(v_scale), index.block_m, index.block_n, kv_stage)
         except RuntimeError as e:
             raise _lib.TmxError(-1, str(e)) from None
         index.built = True
@@ -496,6 +535,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
             raise RuntimeError("attention workspace too small for this index")
     a.partial_o, a.partial_ml = _ptr(part_o), _ptr(part_ml)
     a.flags, a.reserved = int(flags), 0
+    a.kv_stage, a.kv_stage_rows = (kv_stage.data_ptr(), int(kv_stage.shape[1])) if kv_stage is not None else (None, 0)
     with torch.cuda.device(q.device):
         lib = _lib.load()
         entry = lib.tmx_attention_static_ws if static_workspace else lib.tmx_attention
@@ -623,11 +663,15 @@ def eager_attention_f32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale
     return out
 
 
-def alloc_workspace(index: BlockIndex, num_heads: int, head_dim: int, device):
-    """Partial-result buffers for the q-blocks the index splits."""
+def alloc_workspace(index: BlockIndex, num_heads: int, head_dim: int, device, num_kv_heads: Optional[int] = None):
+    """Partial-result buffers for the q-blocks the index splits -- and, with ``num_kv_heads``, the dense causal
+    kernel's staging area as a third member where the index says that staging pays (``index.stage_rows``)."""
     n = max(1, int(index.sizes.num_partials) * num_heads * index.block_m)
-    return (torch.empty((n * head_dim,), dtype=torch.float32, device=device),
-            torch.empty((n * 2,), dtype=torch.float32, device=device))
+    ws = (torch.empty((n * head_dim,), dtype=torch.float32, device=device),
+          torch.empty((n * 2,), dtype=torch.float32, device=device))
+    if num_kv_heads is not None and head_dim == 128 and index.stage_rows > 0:
+        ws = ws + (alloc_kv_stage(index.stage_rows, num_kv_heads, device),)
+    return ws
 
 
 # --------------------------------------------------------------------------- KV cache
