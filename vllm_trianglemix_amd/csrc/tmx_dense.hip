@@ -454,9 +454,11 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
 #pragma unroll
           for (int i = 0; i < 16; ++i) zero[i] = 0.f;
           u32x4_t kf[kQkAhead];
+          // step i: key block i & 1, k-step i >> 1 -- consecutive matrix instructions accumulate into different
+          // blocks (a chain of eight on one block, then eight on the other: 1.4 % slower)
           auto rd = [&](int i, u32x4_t& dst) {
-            if (i < 8) lds_b128_at<cur>(koff[i & 7], dst);
-            else lds_b128_at<cur + 32 * kDRowB>(koff[i & 7], dst);
+            if ((i & 1) == 0) lds_b128_at<cur>(koff[i >> 1], dst);
+            else lds_b128_at<cur + 32 * kDRowB>(koff[i >> 1], dst);
           };
 #pragma unroll
           for (int i = 0; i < kQkAhead; ++i) rd(i, kf[i]);
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void dense_causal_kernel(const DenseParams 
             else if (left == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(f)::"memory");
             else if (left == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f)::"memory");
             else asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(f)::"memory");
-            s[i >> 3] = mfma_qk<BF16>(__builtin_bit_cast(uint4, f), qf[i & 7], (i & 7) == 0 ? zero : s[i >> 3]);
+            s[i & 1] = mfma_qk<BF16>(__builtin_bit_cast(uint4, f), qf[i >> 1], (i >> 1) == 0 ? zero : s[i & 1]);
             if (i + kQkAhead < 16) rd(i + kQkAhead, f);
           }
         }
