@@ -20,6 +20,9 @@ __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p
   const int slot0 = p.part_ptr[qb], np = p.part_ptr[qb + 1] - slot0;
   const int b = p.qb_meta[2 * qb], row0 = p.qb_meta[2 * qb + 1];
   if (row >= p.block_m) return;
+  // the dense causal kernel wrote this request's rows: its pieces were never computed (before any of them is read:
+  // a long causal prompt has thousands of pieces)
+  if (p.dense_on && p.cu_q[b + 1] - p.cu_q[b] >= kDenseMinRows) return;
   const long long stride = (long long)p.H * p.block_m;  // partial rows between consecutive pieces
   const long long prow0 = ((long long)slot0 * p.H + head) * p.block_m + row;
   const float2* mlp = reinterpret_cast<const float2*>(p.partial_ml) + prow0;
@@ -62,7 +65,6 @@ __global__ __launch_bounds__(8 * (D / 4)) void combine_kernel(const AttnParams p
   const int q_start = p.cu_q[b];
   const int q_len = p.cu_q[b + 1] - q_start;
   if (row >= q_len - row0) return;
-  if (p.dense_on && q_len >= kDenseMinRows) return;  // the dense causal kernel wrote this request's rows
   const float inv = 1.0f / l;  // every piece empty for this row: 0 * inf = NaN, as for an unsplit row
   o.x *= inv;
   o.y *= inv;
