@@ -529,7 +529,11 @@ def main():
     if not args.no_baselines and rank == 0 and not fp8:
         # dense-causal baselines at the same shape (attention-op level)
         try:
-            idx_c = build("causal")
+            # (the index a causal layer's step gets from the backend: the dense causal kernel computes the prompt
+            # without an index, so the index leaves it out -- no tile list, no partial-result slots)
+            idx_c = ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], 0, 0, 0, bm, bn,
+                                          ops.MODES["causal"], chunk_tiles=64, block_table=inp["block_table"],
+                                          page_size=PAGE, leave_dense=True)
             # (with the staging area the library sizes for long prompts: K/V rows gathered once per call, V as fp16,
             # and the kernel's tiles then come into LDS by LDS-DMA; the gather is inside the timed call)
             work_c = ops.alloc_workspace(idx_c, H, D, dev, num_kv_heads=Hkv)

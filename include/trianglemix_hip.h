@@ -53,6 +53,9 @@ enum { TMX_F32 = 0, TMX_BF16 = 1, TMX_F16 = 2, TMX_FP8_E4M3 = 3 };
 
 /* attention / index modes */
 enum { TMX_MODE_NONE = 0, TMX_MODE_CAUSAL = 1, TMX_MODE_TRIANGLE = 2 };
+/* Query rows from which a request of a causal launch goes to the dense causal kernel (shorter ones, decode and
+ * speculative decode, stay on the work list). */
+#define TMX_DENSE_MIN_ROWS 17
 
 /* dense mask kinds for tmx_dense_mask */
 enum {
@@ -148,6 +151,14 @@ int tmx_suggest_chunk_tiles(const int32_t* cu_seqlens_q_host, const int32_t* seq
                             int block_m, int block_n, int mode, int tri_min_len, int units_per_item, int num_cus,
                             int* out);
 
+/* The same for an index that leaves the long requests of a causal launch to the dense causal kernel
+ * (tmx_index_t.dense_rows_from): requests with dense_rows_from query rows or more count no q-blocks, tiles,
+ * items or partial slots.  dense_rows_from == 0: tmx_index_sizes. */
+int tmx_index_sizes_without_dense(const int32_t* cu_seqlens_q_host, const int32_t* seq_lens_host,
+                                  const int32_t* full_lens_host /* or NULL */, int batch, int si, int sl, int last,
+                                  int block_m, int block_n, int mode, int tri_min_len, int chunk_tiles,
+                                  int dense_rows_from, tmx_index_sizes_t* out);
+
 typedef struct tmx_index_t {
   /* all (device), int32, sized from tmx_index_sizes_t */
   int32_t* row_ptr;   /* [R + 1] */
@@ -180,6 +191,14 @@ typedef struct tmx_index_t {
   /* Optional (see "Chunked prefill" above): set before the build, read again by tmx_attention. */
   const int32_t* full_lens;           /* (device) [batch] or NULL */
   const int32_t* full_lens_host;      /* host mirror, for the capacity check of the build; or NULL */
+  /* TMX_MODE_CAUSAL only, 0 or TMX_DENSE_MIN_ROWS: requests with at least this many query rows get NO q-blocks (no
+   * tiles, work items or partial slots; sizes from tmx_index_sizes_without_dense).  tmx_attention computes those
+   * requests with its dense causal kernel, which reads no index -- a 32k-token prompt of a layer outside the
+   * triangle set otherwise lists 525k tiles and asks for 4.6 GB of partial results that nobody reads (128k tokens:
+   * 8.4M tiles, 71 GB).  An attention call that cannot run the dense kernel (bias, head size other than 128, query
+   * heads per K/V head not a multiple of 4, more than 512 requests) refuses such an index. */
+  int32_t dense_rows_from;
+  int32_t reserved;
 } tmx_index_t;
 
 /* Builds the index on the device from the device copies of the batch

@@ -1500,6 +1500,92 @@ def test_dense_causal_kernel_matches_oracle_and_work_list(case):
 
 
 @pytest.mark.parametrize("binding", ["torch", "ctypes"])
+def test_causal_index_without_the_dense_kernels_requests(monkeypatch, binding):
+    """leave_dense: the causal index of a step holds only the requests with fewer than 17 query rows (bit-exact
+    against the oracle's index of the batch without the other requests' rows; request numbers and rows as in the
+    whole batch), the attention call computes the others with the dense kernel and gives the same bits as with the
+    full index; a call that cannot run the dense kernel refuses the index."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "_BINDING", binding)
+    H, Hkv, D, page = 8, 2, 128, 16
+    q_lens, seq_lens = [300, 1, 16, 17, 0, 5, 129, 1, 70], [300, 2500, 67, 900, 0, 905, 129, 70, 2111]
+    bm, bn = ops.attention_block_m(H, Hkv), 32
+    cu_h = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    sl_h = np.asarray(seq_lens, np.int32)
+    cu, sld = torch.from_numpy(cu_h).to(DEV), torch.from_numpy(sl_h).to(DEV)
+    chunk = 8
+    idx = ops.build_block_index(cu, sld, cu_h, sl_h, 0, 0, 0, bm, bn, ops.MODES["causal"], chunk_tiles=chunk, leave_dense=True)
+    cu_f, sl_f = ops.without_dense_requests(cu_h, sl_h)
+    qf, sf = np.diff(cu_f).tolist(), sl_f.tolist()
+    row_ptr, col_idx, qb_seq, qb_row0 = orc.block_index_closed_form(qf, sf, 0, 0, 0, bm, bn, orc.MODE_CAUSAL, None)
+    items, part_ptr = orc.work_items(row_ptr, chunk, qb_seq, qb_row0, qf, sf)
+    # (an item carries the first query row of its q-block: a row of the WHOLE batch's q tensor)
+    items = items.copy()
+    items[:, 5] += (cu_h[:-1] - cu_f[:-1])[items[:, 4]]
+    tot = idx.totals.cpu().numpy()
+    assert tot[0] == len(row_ptr) - 1 == idx.sizes.num_qblocks and tot[1] == len(col_idx) == idx.sizes.nnz_tiles
+    assert tot[2] == len(items) == idx.sizes.num_items and tot[3] == part_ptr[-1] == idx.sizes.num_partials
+    assert np.array_equal(idx.row_ptr.cpu().numpy(), row_ptr) and np.array_equal(idx.col_idx.cpu().numpy(), col_idx)
+    meta = idx.qb_meta.cpu().numpy()
+    assert np.array_equal(meta[:, 0], qb_seq) and np.array_equal(meta[:, 1], qb_row0)
+    assert set(meta[:, 0].tolist()) == {1, 2, 5, 7}   # the requests below 17 rows, numbered as in the whole batch
+    assert np.array_equal(idx.items.cpu().numpy(), items) and np.array_equal(idx.part_ptr.cpu().numpy(), part_ptr)
+    full = ops.build_block_index(cu, sld, cu_h, sl_h, 0, 0, 0, bm, bn, ops.MODES["causal"], chunk_tiles=chunk)
+    assert full.sizes.num_partials > 3 * idx.sizes.num_partials and full.sizes.nnz_tiles > 3 * idx.sizes.nnz_tiles
+    # attention: paged cache, both indexes
+    q, ks, vs = _rand_case(321, q_lens, seq_lens, H, Hkv, D)
+    nblk = sum((s + page - 1) // page for s in seq_lens) + 2
+    perm = np.random.default_rng(3).permutation(nblk).astype(np.int32)
+    kc = torch.zeros((nblk, page, Hkv, D), dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    bt = np.zeros((len(seq_lens), max((s + page - 1) // page for s in seq_lens)), np.int32)
+    nxt = 0
+    for b, s in enumerate(seq_lens):
+        for pb in range((s + page - 1) // page):
+            bt[b, pb] = perm[nxt]
+            nxt += 1
+            lo, hi = pb * page, min((pb + 1) * page, s)
+            kc[bt[b, pb], :hi - lo] = _to_dev(ks[b][lo:hi], torch.bfloat16)
+            vc[bt[b, pb], :hi - lo] = _to_dev(vs[b][lo:hi], torch.bfloat16)
+    btd = torch.from_numpy(bt).to(DEV)
+    qd = _to_dev(q, torch.bfloat16)
+    scale = D ** -0.5
+    outs = []
+    for ix in (full, idx):
+        out = torch.full((int(cu_h[-1]), H, D), float("nan"), dtype=torch.float32, device=DEV)
+        ops.attention(qd, kc, vc, out, ix, cu, sld, scale, block_table=btd)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    ref = orc.varlen_gqa_attention(q, lambda b: ks[b], lambda b: vs[b], cu_h, seq_lens, scale, "causal", 0, 0, 0)
+    assert_close(outs[1].cpu().numpy(), ref, "causal launch, index without the dense kernel's requests")
+    # calls that cannot run the dense kernel: a bias, the flag that keeps it off
+    from vllm_trianglemix_amd._lib import TMX_ATTN_NO_DENSE
+    with pytest.raises(RuntimeError):
+        ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, flags=TMX_ATTN_NO_DENSE)
+    with pytest.raises(RuntimeError):
+        ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd,
+                      bias=torch.zeros((2200, 2600), dtype=torch.float32, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.build_block_index(cu, sld, cu_h, sl_h, 4, 32, 64, bm, bn, ops.MODES["triangle"], leave_dense=True)
+    # a step of long prompts only: an empty index, the dense kernel alone
+    q2, s2 = [700, 64], [700, 1000]
+    cu2_h, sl2_h = np.asarray([0, 700, 764], np.int32), np.asarray(s2, np.int32)
+    e = ops.build_block_index(torch.from_numpy(cu2_h).to(DEV), torch.from_numpy(sl2_h).to(DEV), cu2_h, sl2_h, 0, 0, 0, bm, bn,
+                              ops.MODES["causal"], chunk_tiles=chunk, leave_dense=True)
+    assert (e.sizes.num_qblocks, e.sizes.num_items, e.sizes.num_partials) == (0, 0, 0)
+    qq, kk, vv = _rand_case(77, q2, s2, H, Hkv, D)
+    got = _run_varlen(ops, qq, kk, vv, q2, s2, scale, "causal", (0, 0, 0), paged=True, page_size=16, chunk=chunk)
+    kd, vd = _to_dev(np.concatenate(kk, 0), torch.bfloat16), _to_dev(np.concatenate(vv, 0), torch.bfloat16)
+    cu_k = torch.from_numpy(np.concatenate([[0], np.cumsum(s2)]).astype(np.int32)).to(DEV)
+    out = torch.full((764, H, D), float("nan"), dtype=torch.float32, device=DEV)
+    ops.attention(_to_dev(qq, torch.bfloat16), kd, vd, out, e, torch.from_numpy(cu2_h).to(DEV), torch.from_numpy(sl2_h).to(DEV),
+                  scale, cu_seqlens_k=cu_k)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), got)
+
+
+@pytest.mark.parametrize("binding", ["torch", "ctypes"])
 def test_dense_causal_staging_area(monkeypatch, binding):
     """The staging area of the dense causal kernel through both bindings: sized by dense_stage_rows (long prompts
     only by default; every request with 17 query rows or more when asked), handed over as kv_stage or as the third

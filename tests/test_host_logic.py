@@ -435,3 +435,26 @@ def test_dense_stage_rows_host_rule():
     assert ops.dense_stage_rows([0], []) == 0
     with pytest.raises(RuntimeError):
         ops.dense_stage_rows([0, 5], [5, 6])
+
+
+def test_index_sizes_without_the_dense_kernels_requests():
+    """An index that leaves the requests of 17 query rows or more to the dense causal kernel is sized like the
+    index of the batch without those requests' rows."""
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        B = int(rng.integers(1, 12))
+        q = rng.choice([0, 1, 1, 3, 16, 17, 18, 64, 700, 5000], size=B)
+        ctx = rng.choice([0, 0, 5, 100, 4000], size=B)
+        cu = np.concatenate([[0], np.cumsum(q)]).astype(np.int32)
+        sl = (q + ctx).astype(np.int32)
+        cu_f, sl_f = ops.without_dense_requests(cu, sl)
+        assert np.array_equal(np.diff(cu_f), np.where(q >= 17, 0, q)) and np.array_equal(sl_f, np.where(q >= 17, ctx, q + ctx))
+        for chunk in (8, 64):
+            a = ops.index_sizes(cu, sl, 0, 0, 0, 32, 32, ops.MODES["causal"], chunk_tiles=chunk, dense_rows_from=17)
+            b = ops.index_sizes(cu_f, sl_f, 0, 0, 0, 32, 32, ops.MODES["causal"], chunk_tiles=chunk)
+            for f in ("num_qblocks", "nnz_tiles", "num_items", "num_partials", "num_split_qblocks"):
+                assert getattr(a, f) == getattr(b, f), (f, q, ctx)
+    # one 32k prompt of a layer outside the triangle set: nothing left to list
+    sz = ops.index_sizes([0, 32768], [32768], 0, 0, 0, 32, 32, ops.MODES["causal"], chunk_tiles=64, dense_rows_from=17)
+    assert (sz.num_qblocks, sz.nnz_tiles, sz.num_items, sz.num_partials) == (0, 0, 0, 0)
+    assert ops.index_sizes([0, 32768], [32768], 0, 0, 0, 32, 32, ops.MODES["causal"], chunk_tiles=64).num_partials == 8640

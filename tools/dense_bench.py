@@ -17,9 +17,10 @@ H, Hkv, D = 32, 8, 128
 inp = bench.make_inputs(ops, dev, n, 1, H, Hkv, D, seed=0, fp8=False)
 si, sl, last = bench.PATTERN
 bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
-chunk = ops.suggest_chunk_tiles(inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn, ops.MODES["causal"], ops.units_per_item(H, Hkv))
-idx = ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], si, sl, last, bm, bn, ops.MODES["causal"],
-                            chunk_tiles=chunk, block_table=inp["block_table"], page_size=bench.PAGE)
+# (TMX_DENSE_FULL_INDEX=1: the index lists the prompt's tiles although the dense kernel does not read them)
+leave = os.environ.get("TMX_DENSE_FULL_INDEX", "0") != "1"
+idx = ops.build_block_index(inp["cu"], inp["sl"], inp["cu_h"], inp["sl_h"], 0, 0, 0, bm, bn, ops.MODES["causal"],
+                            chunk_tiles=64, block_table=inp["block_table"], page_size=bench.PAGE, leave_dense=leave)
 staged = os.environ.get("TMX_DENSE_STAGE", "1") != "0"
 if os.environ.get("TMX_DENSE_STAGE") == "2":  # staged whatever the length (the library's default: from 4096 rows on)
     idx.stage_rows = ops.dense_stage_rows(inp["cu_h"], inp["sl_h"], 0)

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "tmx_replace_neg_inf", "tmx_index_sizes", "tmx_build_block_index", "tmx_attention", "tmx_reshape_and_cache",
     "tmx_reshape_and_cache_fp8", "tmx_gather_dequant_kv_fp8", "tmx_suggest_chunk_tiles",
     "tmx_attention_static_ws", "tmx_static_workspace_bytes", "tmx_static_workspace_warmup", "tmx_eager_attention_f32",
-    "tmx_decode_attention", "tmx_decode_workspace_rows", "tmx_dense_stage_rows",
+    "tmx_decode_attention", "tmx_decode_workspace_rows", "tmx_dense_stage_rows", "tmx_index_sizes_without_dense",
 )
 
 
@@ -47,7 +47,8 @@ class Index(Structure):
                 ("si", c_int32), ("sl", c_int32), ("last", c_int32), ("batch", c_int32),
                 ("tri_min_len", c_int32), ("pages_page_size", c_int32),
                 ("tile_pages", c_void_p), ("pages_block_table", c_void_p), ("pages_block_table_stride", c_int64),
-                ("full_lens", c_void_p), ("full_lens_host", c_void_p)]
+                ("full_lens", c_void_p), ("full_lens_host", c_void_p),
+                ("dense_rows_from", c_int32), ("reserved", c_int32)]
 
 
 class AttentionArgs(Structure):
@@ -94,6 +95,7 @@ class DecodeArgs(Structure):
 
 TMX_ATTN_SKIP_COMBINE, TMX_ATTN_ONLY_COMBINE, TMX_ATTN_SHORT_QUERIES, TMX_ATTN_NO_BAND, TMX_ATTN_NO_DENSE = 1, 2, 4, 8, 16
 TMX_ATTN_NO_DECODE, TMX_ATTN_DECODE_ONLY, TMX_ATTN_DECODE_VALU = 32, 64, 128
+TMX_DENSE_MIN_ROWS = 17  # query rows from which a request of a causal launch goes to the dense causal kernel
 TMX_ATTN_BUILD_INDEX = 256  # the index is still to be built: this call builds it (inside the attention launch where it can)
 
 
@@ -119,6 +121,8 @@ def load() -> ctypes.CDLL:
     lib.tmx_replace_neg_inf.argtypes = [c_void_p, c_int64, c_int, c_float, c_void_p]
     lib.tmx_index_sizes.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     POINTER(IndexSizes)]
+    lib.tmx_index_sizes_without_dense.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                  c_int, c_int, c_int, POINTER(IndexSizes)]
     lib.tmx_suggest_chunk_tiles.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_int, c_int, c_int, c_int, POINTER(c_int)]
     lib.tmx_build_block_index.argtypes = [POINTER(Index), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

@@ -126,30 +126,38 @@ class TriangleMixAttentionMetadata:
     _workspaces: Dict[Tuple, tuple] = field(default_factory=dict, repr=False)
 
     def block_index(self, mode: str, pattern: Tuple[int, int, int], num_heads: int, num_kv_heads: int,
-                    tri_min_len: int, fp8_cache: bool = False) -> "ops.BlockIndex":
+                    tri_min_len: int, fp8_cache: bool = False, dense_kernel: bool = False) -> "ops.BlockIndex":
         """The step's index for (mode, pattern, head grouping): built on first use, then
         shared by every layer that asks for the same one (the mask does not depend on the layer
-        beyond the triangle/dense choice)."""
+        beyond the triangle/dense choice).  ``dense_kernel``: the layer's causal attention call can run the dense
+        causal kernel; the causal index then leaves the requests of 17 query rows or more out (no tile lists, work
+        items or partial-result slots for prompts that kernel computes without an index)."""
         block_m = ops.attention_block_m(num_heads, num_kv_heads)
         # a step of one-row requests out of an fp8 cache is cut for the decode kernel's workgroups (8 query heads
         # each when the group size allows): half the bytes per key, so twice the pieces keep the chip busy
         units = ops.units_per_item(num_heads, num_kv_heads)
         if fp8_cache and self.max_query_len == 1:
             units = ops.decode_units_per_item(num_heads, num_kv_heads)
-        key = (mode, pattern, block_m, tri_min_len, units)
+        leave_dense = bool(dense_kernel and mode == "causal" and len(self.seq_lens_cpu) <= 512)
+        key = (mode, pattern, block_m, tri_min_len, units, leave_dense)
         idx = self._indices.get(key)
         if idx is None:
             # piece length for this batch and head grouping: one piece of the dense rows per CU when the step
-            # also holds sparse rows, 128-tile pieces for pure decode steps (tmx_suggest_chunk_tiles)
-            chunk = ops.suggest_chunk_tiles(self.query_start_loc_cpu, self.seq_lens_cpu, pattern[0], pattern[1],
+            # also holds sparse rows, 128-tile pieces for pure decode steps (tmx_suggest_chunk_tiles); an index
+            # without the dense kernel's requests is cut for the requests that remain
+            cu_s, sl_s = ((self.query_start_loc_cpu, self.seq_lens_cpu) if not leave_dense else
+                          ops.without_dense_requests(self.query_start_loc_cpu, self.seq_lens_cpu))
+            chunk = ops.suggest_chunk_tiles(cu_s, sl_s, pattern[0], pattern[1],
                                             pattern[2], block_m, ops.attention_block_n(), ops.MODES[mode],
-                                            units, tri_min_len=tri_min_len, full_lens_cpu=self.prompt_lens_cpu)
+                                            units, tri_min_len=tri_min_len,
+                                            full_lens_cpu=None if leave_dense else self.prompt_lens_cpu)
             idx = ops.build_block_index(self.query_start_loc, self.seq_lens, self.query_start_loc_cpu,
                                         self.seq_lens_cpu, pattern[0], pattern[1], pattern[2], block_m,
                                         ops.attention_block_n(), ops.MODES[mode], chunk_tiles=chunk,
                                         tri_min_len=tri_min_len,
                                         block_table=self.block_table, page_size=self.page_size,
-                                        full_lens=self.prompt_lens, full_lens_cpu=self.prompt_lens_cpu)
+                                        full_lens=self.prompt_lens, full_lens_cpu=self.prompt_lens_cpu,
+                                        leave_dense=leave_dense)
             self._indices[key] = idx
         return idx
 
@@ -422,7 +430,8 @@ class TriangleMixAttentionImpl(_ImplBase):
         mode = "triangle" if self.use_triangle else "causal"
         pattern = self.pattern if self.use_triangle else (0, 0, 0)
         tri_min_len = self.tri_min_len if self.use_triangle else 0
-        idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len)
+        idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len,
+                            dense_kernel=self._dense_kernel_ok())
         ws = m.workspace(idx, self.num_heads, self.head_size, q.device, self.num_kv_heads)
         k_rows = v_rows = None
         if writes_cache and n_tok > 0:
@@ -457,6 +466,11 @@ class TriangleMixAttentionImpl(_ImplBase):
         ops.attention(q, key_cache, value_cache, out, idx, m.query_start_loc, m.seq_lens, self.scale,
                       block_table=m.block_table, workspace=ws, flags=_step_flags(m))
         return output
+
+    def _dense_kernel_ok(self) -> bool:
+        """A causal attention call of this layer can run the dense causal kernel (head size 128, query-head groups
+        that are multiples of 4; the backend passes no bias): its index then leaves the long requests out."""
+        return self.head_size == 128 and (self.num_heads // self.num_kv_heads) % 4 == 0
 
     def _decode_fixed_ok(self) -> bool:
         """The fixed-shape decode launch covers head size 128 and query-head groups that are multiples of 4; a decode
@@ -512,7 +526,8 @@ class TriangleMixAttentionImpl(_ImplBase):
         mode = "triangle" if self.use_triangle else "causal"
         pattern = self.pattern if self.use_triangle else (0, 0, 0)
         tri_min_len = self.tri_min_len if self.use_triangle else 0
-        idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len, fp8_cache=self.head_size == 128)
+        idx = m.block_index(mode, pattern, self.num_heads, self.num_kv_heads, tri_min_len, fp8_cache=self.head_size == 128,
+                            dense_kernel=self._dense_kernel_ok())
         ws = m.workspace(idx, self.num_heads, self.head_size, q.device, self.num_kv_heads)
         if self.head_size == 128:
             # the attention kernel reads the fp8 pages in place and descales inside its tile loop

@@ -33,7 +33,15 @@ int tmx_attention_block_n(void) { return tmx::kBlockN; }
 int tmx_index_sizes(const int32_t* cu_q, const int32_t* seq_lens, const int32_t* full_lens, int batch, int si,
                     int sl, int last, int block_m, int block_n, int mode, int tri_min_len, int chunk_tiles,
                     tmx_index_sizes_t* out) {
+  return tmx_index_sizes_without_dense(cu_q, seq_lens, full_lens, batch, si, sl, last, block_m, block_n, mode, tri_min_len,
+                                       chunk_tiles, 0, out);
+}
+
+int tmx_index_sizes_without_dense(const int32_t* cu_q, const int32_t* seq_lens, const int32_t* full_lens, int batch, int si,
+                                  int sl, int last, int block_m, int block_n, int mode, int tri_min_len, int chunk_tiles,
+                                  int dense_rows_from, tmx_index_sizes_t* out) {
   TMX_CHECK_ARG(out != nullptr, "tmx_index_sizes: out is NULL");
+  TMX_CHECK_ARG(dense_rows_from >= 0, "tmx_index_sizes: dense_rows_from is negative");
   TMX_CHECK_ARG(batch >= 0 && (batch == 0 || (cu_q && seq_lens)), "tmx_index_sizes: NULL batch arrays");
   TMX_CHECK_ARG(block_m > 0 && block_n > 0 && chunk_tiles > 0, "tmx_index_sizes: block sizes must be positive");
   TMX_CHECK_ARG(mode >= TMX_MODE_NONE && mode <= TMX_MODE_TRIANGLE, "tmx_index_sizes: bad mode %d", mode);
@@ -42,6 +50,7 @@ int tmx_index_sizes(const int32_t* cu_q, const int32_t* seq_lens, const int32_t*
     const int ql = cu_q[b + 1] - cu_q[b];
     const int n = seq_lens[b];
     TMX_CHECK_ARG(ql >= 0 && n >= ql, "tmx_index_sizes: request %d has q_len %d, seq_len %d", b, ql, n);
+    if (dense_rows_from > 0 && ql >= dense_rows_from) continue;  // left to the dense causal kernel: no q-blocks
     const int ctx = n - ql;
     const int nf = full_lens ? tmx::imax(n, full_lens[b]) : n;
     const int m = tmx::effective_mode(mode, nf, tri_min_len);

@@ -65,8 +65,9 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   TMX_CHECK_ARG(a->batch >= 0 && a->total_q >= 0 && a->num_items >= 0 && a->num_partials >= 0 &&
                     a->num_split_qblocks >= 0,
                 "tmx_attention: negative size");
-  if (a->total_q == 0 || a->num_items == 0) return TMX_OK;
   const tmx_index_t* ix = a->index;
+  // (an index without the dense causal kernel's requests may be empty: that kernel still has work)
+  if (a->total_q == 0 || (a->num_items == 0 && !(ix != nullptr && ix->dense_rows_from != 0))) return TMX_OK;
   TMX_CHECK_ARG(ix != nullptr, "tmx_attention: index is NULL");
   const int G = a->num_heads / a->num_kv_heads;
   TMX_CHECK_ARG(ix->block_n == kBlockN && ix->block_m == block_m_for_group(G),
@@ -231,6 +232,16 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
                 a->total_q >= kDenseMinRows && !(a->flags & (TMX_ATTN_SHORT_QUERIES | TMX_ATTN_NO_DENSE | TMX_ATTN_ONLY_COMBINE)))
                    ? 1
                    : 0;
+  static_assert(kDenseMinRows == TMX_DENSE_MIN_ROWS, "the public constant is the kernel's");
+  // an index without the long requests of a causal launch: the dense kernel has to be there for them
+  if (ix->dense_rows_from != 0) {
+    TMX_CHECK_ARG(ix->dense_rows_from == kDenseMinRows && a->mode == TMX_MODE_CAUSAL,
+                  "tmx_attention: index->dense_rows_from is 0 or %d, the latter with TMX_MODE_CAUSAL only", kDenseMinRows);
+    TMX_CHECK_SUPPORTED(p.dense_on || a->total_q < kDenseMinRows,
+                        "tmx_attention: the index leaves requests of %d query rows or more to the dense causal kernel, which "
+                        "this call cannot run (bias, head size other than 128, query heads per K/V head not a multiple of 4, "
+                        "more than %d requests, or a flag that keeps it off)", kDenseMinRows, kDenseMaxBatch);
+  }
   p.band_rl = 0;
   p.band_tail0 = 0;
   p.band_rls = 0;
@@ -321,6 +332,7 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
     const int rc = launch_dense_causal(d, a->io_dtype == TMX_BF16, paged, s);
     if (rc != TMX_OK) return rc;
   }
+  if (a->num_items == 0) return TMX_OK;  // (an index that left every request to the dense kernel)
   // Decode kernel: one-row requests whose row is dense (every decode step of the default pattern, every row of
   // a causal layer) stream their K/V straight into registers there.  A step of one-row requests only is all
   // the kernel's; in a mixed step its grid also covers the other requests' items (workgroups that return at

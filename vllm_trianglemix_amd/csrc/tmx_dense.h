@@ -9,7 +9,7 @@ namespace tmx {
 
 // Requests with at least this many query rows take the dense kernel; shorter ones (decode, speculative
 // decode) stay on the work-list kernel, whose 16-row waves waste nothing on them.
-constexpr int kDenseMinRows = 17;
+constexpr int kDenseMinRows = 17;  // (TMX_DENSE_MIN_ROWS of the public header: checked where both are seen)
 // The kernel keeps one block count per request in LDS.
 constexpr int kDenseMaxBatch = 512;
 

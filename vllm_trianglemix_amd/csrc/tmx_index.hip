@@ -49,7 +49,8 @@ __global__ __launch_bounds__(1024) void index_block_kernel(IndexParams p) {
     int nqb = 0;
     if (b < p.batch) {
       const int q0 = p.cu_q[b], q1 = p.cu_q[b + 1];
-      const int rows = imax(0, q1 - q0);
+      int rows = imax(0, q1 - q0);
+      if (p.dense_rows_from > 0 && rows >= p.dense_rows_from) rows = 0;
       nqb = p.bm_shift >= 0 ? (rows + p.block_m - 1) >> p.bm_shift : ceil_div(rows, p.block_m);
       if (cached) {
         const int n = p.seq_lens[b];
@@ -214,6 +215,9 @@ int index_params_from(const tmx_index_t* idx, const int32_t* cu_q_dev, const int
                 "tmx_build_block_index: block_m / block_n / chunk_tiles must be positive");
   TMX_CHECK_ARG(idx->mode >= TMX_MODE_NONE && idx->mode <= TMX_MODE_TRIANGLE, "tmx_build_block_index: bad mode %d",
                 idx->mode);
+  TMX_CHECK_ARG(idx->dense_rows_from == 0 || (idx->dense_rows_from == TMX_DENSE_MIN_ROWS && idx->mode == TMX_MODE_CAUSAL),
+                "tmx_build_block_index: dense_rows_from is 0 or TMX_DENSE_MIN_ROWS (%d), the latter with TMX_MODE_CAUSAL only",
+                TMX_DENSE_MIN_ROWS);
   TMX_CHECK_ARG(idx->totals && idx->scratch && idx->row_ptr && idx->part_ptr,
                 "tmx_build_block_index: NULL totals / scratch / row_ptr / part_ptr");
   TMX_CHECK_ARG(idx->batch == 0 || (cu_q_dev && seq_lens_dev), "tmx_build_block_index: NULL device batch arrays");
@@ -227,6 +231,7 @@ int index_params_from(const tmx_index_t* idx, const int32_t* cu_q_dev, const int
   p.cu_q = cu_q_dev;
   p.seq_lens = seq_lens_dev;
   p.full_lens = idx->full_lens;
+  p.dense_rows_from = idx->dense_rows_from;
   p.row_ptr = idx->row_ptr;
   p.col_idx = idx->col_idx;
   p.qb_meta = idx->qb_meta;
@@ -283,8 +288,9 @@ extern "C" int tmx_build_block_index(tmx_index_t* idx, const int32_t* cu_q_dev, 
   // (full_lens without its host mirror: the sizes cannot be recomputed here, the check is skipped)
   if (cu_q_host && seq_lens_host && (idx->full_lens == nullptr || idx->full_lens_host != nullptr)) {
     tmx_index_sizes_t sz;
-    int rc = tmx_index_sizes(cu_q_host, seq_lens_host, idx->full_lens ? idx->full_lens_host : nullptr, idx->batch, idx->si, idx->sl, idx->last, idx->block_m,
-                             idx->block_n, idx->mode, idx->tri_min_len, idx->chunk_tiles, &sz);
+    int rc = tmx_index_sizes_without_dense(cu_q_host, seq_lens_host, idx->full_lens ? idx->full_lens_host : nullptr, idx->batch, idx->si,
+                                           idx->sl, idx->last, idx->block_m, idx->block_n, idx->mode, idx->tri_min_len, idx->chunk_tiles,
+                                           idx->dense_rows_from, &sz);
     if (rc != TMX_OK) return rc;
     if (sz.num_qblocks > idx->cap_qblocks || sz.nnz_tiles > idx->cap_nnz || sz.num_items > idx->cap_items ||
         sz.num_split_qblocks > idx->cap_split) {

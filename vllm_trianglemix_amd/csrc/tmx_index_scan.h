@@ -92,6 +92,7 @@ struct IndexParams {
   int cap_qblocks, cap_nnz, cap_items, cap_split;
   int fused;  // pass 2 inside the scan launch (host: cap_qblocks <= 1024)
   int bn_shift, bm_shift;  // log2 of block_n / block_m when powers of two, else -1
+  int dense_rows_from;     // > 0: requests with at least this many query rows own no q-blocks (tmx_index_t.dense_rows_from)
 };
 
 // Position of a q-block's first work item.  The list starts with the pieces of all split q-blocks (the
@@ -205,7 +206,8 @@ __device__ __forceinline__ void index_scan_body(const IndexParams& p, IndexScanS
     int nqb = 0;
     if (b < p.batch) {
       const int q0 = p.cu_q[b], q1 = p.cu_q[b + 1];
-      const int rows = imax(0, q1 - q0);
+      int rows = imax(0, q1 - q0);
+      if (p.dense_rows_from > 0 && rows >= p.dense_rows_from) rows = 0;
       nqb = p.bm_shift >= 0 ? (rows + p.block_m - 1) >> p.bm_shift : ceil_div(rows, p.block_m);
       if (cached) {
         const int n = p.seq_lens[b];

@@ -47,7 +47,7 @@ void fill_index(tmx_index_t& ix, const std::vector<Tensor>& b, const std::option
                 const std::optional<Tensor>& pages_block_table, int64_t page_size, int64_t si, int64_t sl,
                 int64_t last, int64_t block_m, int64_t block_n, int64_t mode, int64_t tri_min_len,
                 int64_t chunk_tiles, int64_t batch, const std::optional<Tensor>& full_lens = std::nullopt,
-                const std::optional<Tensor>& full_lens_cpu = std::nullopt) {
+                const std::optional<Tensor>& full_lens_cpu = std::nullopt, int64_t dense_rows_from = 0) {
   TORCH_CHECK(b.size() == 8, "trianglemix: the index is a list of 8 tensors");
   ix = tmx_index_t{};
   ix.row_ptr = i32(b[0]);
@@ -84,17 +84,19 @@ void fill_index(tmx_index_t& ix, const std::vector<Tensor>& b, const std::option
   }
   ix.full_lens = i32_opt(full_lens);
   ix.full_lens_host = i32_opt(full_lens_cpu);
+  ix.dense_rows_from = (int32_t)dense_rows_from;
 }
 
 // Exact buffer sizes from the host copies of the batch: [R, nnz, items, partials, split q-blocks, max tiles].
 std::vector<int64_t> index_sizes(const Tensor& cu_seqlens_q_cpu, const Tensor& seq_lens_cpu, int64_t si, int64_t sl,
                                  int64_t last, int64_t block_m, int64_t block_n, int64_t mode, int64_t tri_min_len,
-                                 int64_t chunk_tiles, const std::optional<Tensor>& full_lens_cpu) {
+                                 int64_t chunk_tiles, const std::optional<Tensor>& full_lens_cpu, int64_t dense_rows_from) {
   TORCH_CHECK(cu_seqlens_q_cpu.is_cpu() && seq_lens_cpu.is_cpu() && (!full_lens_cpu.has_value() || full_lens_cpu->is_cpu()),
               "trianglemix: host tensors expected");
   tmx_index_sizes_t sz;
-  check(tmx_index_sizes(i32(cu_seqlens_q_cpu), i32(seq_lens_cpu), i32_opt(full_lens_cpu), (int)seq_lens_cpu.numel(), (int)si, (int)sl,
-                        (int)last, (int)block_m, (int)block_n, (int)mode, (int)tri_min_len, (int)chunk_tiles, &sz));
+  check(tmx_index_sizes_without_dense(i32(cu_seqlens_q_cpu), i32(seq_lens_cpu), i32_opt(full_lens_cpu), (int)seq_lens_cpu.numel(),
+                                      (int)si, (int)sl, (int)last, (int)block_m, (int)block_n, (int)mode, (int)tri_min_len,
+                                      (int)chunk_tiles, (int)dense_rows_from, &sz));
   return {sz.num_qblocks, sz.nnz_tiles, sz.num_items, sz.num_partials, sz.num_split_qblocks, sz.max_tiles_per_qblock};
 }
 
@@ -115,11 +117,11 @@ void build_block_index(std::vector<Tensor> index, const std::optional<Tensor>& t
                        const std::optional<Tensor>& block_table, int64_t page_size, int64_t si, int64_t sl,
                        int64_t last, int64_t block_m, int64_t block_n, int64_t mode, int64_t tri_min_len,
                        int64_t chunk_tiles, const std::optional<Tensor>& full_lens,
-                       const std::optional<Tensor>& full_lens_cpu) {
+                       const std::optional<Tensor>& full_lens_cpu, int64_t dense_rows_from) {
   const DeviceGuard guard(cu_seqlens_q.device());
   tmx_index_t ix;
   fill_index(ix, index, tile_pages, block_table, page_size, si, sl, last, block_m, block_n, mode, tri_min_len,
-             chunk_tiles, seq_lens.numel(), full_lens, full_lens_cpu);
+             chunk_tiles, seq_lens.numel(), full_lens, full_lens_cpu, dense_rows_from);
   check(tmx_build_block_index(&ix, i32(cu_seqlens_q), i32(seq_lens), i32(cu_seqlens_q_cpu), i32(seq_lens_cpu),
                               stream_of(cu_seqlens_q)));
 }
@@ -141,7 +143,7 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
                int64_t num_partials, int64_t num_split_qblocks, const std::optional<Tensor>& full_lens,
                int64_t flags, int64_t nnz_tiles, const std::optional<Tensor>& k_new, const std::optional<Tensor>& v_new,
                const std::optional<Tensor>& cache_slots, double k_scale, double v_scale, int64_t index_block_m,
-               int64_t index_block_n, const std::optional<Tensor>& kv_stage) {
+               int64_t index_block_n, const std::optional<Tensor>& kv_stage, int64_t index_dense_rows_from) {
   TORCH_CHECK(query.is_cuda(), "trianglemix: query must be on a HIP device (there is no CPU path)");
   const DeviceGuard guard(query.device());
   TORCH_CHECK(query.dim() == 3 && out.dim() == 3 && query.sizes() == out.sizes(), "trianglemix: query / out must both be [T, H, D]");
@@ -179,7 +181,7 @@ void attention(Tensor& out, const Tensor& query, const Tensor& key_cache, const 
   const int64_t block_m = index_block_m > 0 ? index_block_m : tmx_attention_block_m((int)query.size(1), (int)hkv);
   fill_index(ix, index, tile_pages, block_table, paged ? key_cache.size(1) : 0, si, sl, last, block_m,
              index_block_n > 0 ? index_block_n : tmx_attention_block_n(), mode, tri_min_len, chunk_tiles, seq_lens.numel(),
-             full_lens);
+             full_lens, std::nullopt, index_dense_rows_from);
   tmx_attention_args_t a{};
   a.struct_size = sizeof(a);
   a.io_dtype = dtype_code(query);
@@ -425,7 +427,7 @@ void gather_dequant_kv_fp8(Tensor& k_rows, Tensor& v_rows, const Tensor& key_cac
 
 TORCH_LIBRARY(_trianglemix_C, m) {
   m.def("trianglemix_index_sizes(Tensor cu_seqlens_q_cpu, Tensor seq_lens_cpu, int si, int sl, int last, int block_m, "
-        "int block_n, int mode, int tri_min_len, int chunk_tiles, Tensor? full_lens_cpu=None) -> int[]");
+        "int block_n, int mode, int tri_min_len, int chunk_tiles, Tensor? full_lens_cpu=None, int dense_rows_from=0) -> int[]");
   m.impl("trianglemix_index_sizes", c10::DispatchKey::CPU, &index_sizes);
   m.def("trianglemix_suggest_chunk_tiles(Tensor cu_seqlens_q_cpu, Tensor seq_lens_cpu, int si, int sl, int last, "
         "int block_m, int block_n, int mode, int tri_min_len, int units_per_item, int num_cus, "
@@ -434,7 +436,7 @@ TORCH_LIBRARY(_trianglemix_C, m) {
   m.def("trianglemix_build_block_index(Tensor(a!)[] index, Tensor? tile_pages, Tensor cu_seqlens_q, Tensor seq_lens, "
         "Tensor cu_seqlens_q_cpu, Tensor seq_lens_cpu, Tensor? block_table, int page_size, int si, int sl, int last, "
         "int block_m, int block_n, int mode, int tri_min_len, int chunk_tiles, Tensor? full_lens=None, "
-        "Tensor? full_lens_cpu=None) -> ()");
+        "Tensor? full_lens_cpu=None, int dense_rows_from=0) -> ()");
   m.impl("trianglemix_build_block_index", c10::DispatchKey::CUDA, &build_block_index);
   m.def("trianglemix_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, Tensor? block_table, "
         "Tensor cu_seqlens_q, Tensor seq_lens, Tensor? cu_seqlens_k, Tensor[] index, Tensor? tile_pages, "
@@ -442,7 +444,7 @@ TORCH_LIBRARY(_trianglemix_C, m) {
         "int tri_min_len, int chunk_tiles, int num_items, int num_partials, int num_split_qblocks, "
         "Tensor? full_lens=None, int flags=0, int nnz_tiles=0, Tensor? k_new=None, Tensor? v_new=None, "
         "Tensor? cache_slots=None, float k_scale=1.0, float v_scale=1.0, int index_block_m=0, int index_block_n=0, "
-        "Tensor? kv_stage=None) -> ()");
+        "Tensor? kv_stage=None, int index_dense_rows_from=0) -> ()");
   m.impl("trianglemix_attention", c10::DispatchKey::CUDA, &attention);
   m.def("trianglemix_decode_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, Tensor block_table, "
         "Tensor seq_lens, Tensor! partial_o, Tensor! partial_ml, float scale, Tensor? k_new=None, Tensor? v_new=None, "

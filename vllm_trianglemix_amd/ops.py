@@ -95,9 +95,11 @@ def attention_block_n() -> int:
 
 def index_sizes(cu_seqlens_q_cpu, seq_lens_cpu, si: int, sl: int, last: int, block_m: int, block_n: int,
                 mode: int, chunk_tiles: int = DEFAULT_CHUNK_TILES, tri_min_len: int = 0,
-                full_lens_cpu=None) -> IndexSizes:
+                full_lens_cpu=None, dense_rows_from: int = 0) -> IndexSizes:
     """Exact buffer sizes of the index, from the host copies of the batch.  ``full_lens_cpu`` (optional):
-    the length every sequence will have once its prompt is complete (chunked prefill)."""
+    the length every sequence will have once its prompt is complete (chunked prefill).  ``dense_rows_from``
+    (0 or ``TMX_DENSE_MIN_ROWS``): requests with that many query rows or more count nothing (an index that leaves
+    them to the dense causal kernel)."""
     cu = np.ascontiguousarray(np.asarray(cu_seqlens_q_cpu), dtype=np.int32)
     sl_ = np.ascontiguousarray(np.asarray(seq_lens_cpu), dtype=np.int32)
     if cu.ndim != 1 or sl_.ndim != 1 or cu.shape[0] != sl_.shape[0] + 1:
@@ -108,10 +110,9 @@ def index_sizes(cu_seqlens_q_cpu, seq_lens_cpu, si: int, sl: int, last: int, blo
         if fl.shape != sl_.shape:
             raise RuntimeError("full_lens must have one entry per request")
     sz = IndexSizes()
-    check(_lib.load().tmx_index_sizes(_np_ptr(cu), _np_ptr(sl_),
-                                      None if fl is None else _np_ptr(fl), int(sl_.shape[0]), si, sl, last, block_m, block_n, mode, tri_min_len,
-                                      chunk_tiles,
-                                      ctypes.byref(sz)))
+    check(_lib.load().tmx_index_sizes_without_dense(_np_ptr(cu), _np_ptr(sl_), None if fl is None else _np_ptr(fl),
+                                                    int(sl_.shape[0]), si, sl, last, block_m, block_n, mode, tri_min_len,
+                                                    chunk_tiles, int(dense_rows_from), ctypes.byref(sz)))
     return sz
 
 
@@ -233,7 +234,8 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
                       si: int, sl: int, last: int, block_m: int, block_n: int, mode: int,
                       chunk_tiles: int = DEFAULT_CHUNK_TILES, tri_min_len: int = 0,
                       block_table: Optional[torch.Tensor] = None, page_size: int = 0,
-                      full_lens: Optional[torch.Tensor] = None, full_lens_cpu=None, defer: bool = False) -> BlockIndex:
+                      full_lens: Optional[torch.Tensor] = None, full_lens_cpu=None, defer: bool = False,
+                      leave_dense: bool = False) -> BlockIndex:
     """Build the packed block-sparse index on the device (one allocation, at most two launches, no
     host synchronisation; buffer sizes come from the host copies).  ``defer``: only size, allocate and describe
     the index; the first ``attention`` call that gets it builds it as part of its own work
@@ -243,7 +245,12 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
     pages of every listed tile are resolved as well (paged K/V, ``block_n`` 32).
     ``full_lens`` (int32 ``[B]`` on the device, with its host copy): the length each
     sequence will have once its prompt is complete, so that the steps of a chunked
-    prefill attend exactly as the one-step prefill of the whole prompt does."""
+    prefill attend exactly as the one-step prefill of the whole prompt does.
+    ``leave_dense`` (causal mode): requests with ``TMX_DENSE_MIN_ROWS`` (17) query rows or more get no q-blocks at
+    all -- the attention call computes them with its dense causal kernel, which reads no index.  For callers that
+    know the call can run that kernel (head size 128, query heads per K/V head a multiple of 4, no bias, at most 512
+    requests; ``attention`` refuses the index otherwise): a long prompt of a layer outside the triangle set then
+    costs neither the list of its half a million tiles nor gigabytes of partial-result slots nobody reads."""
     _require_gpu(cu_seqlens_q, "cu_seqlens_q")
     _require_gpu(seq_lens, "seq_lens")
     if cu_seqlens_q.dtype != torch.int32 or seq_lens.dtype != torch.int32:
@@ -262,7 +269,10 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
         fl_h = np.ascontiguousarray(np.asarray(full_lens_cpu), dtype=np.int32)
         if full_lens.dtype != torch.int32 or full_lens.numel() != batch or fl_h.shape[0] != batch:
             raise RuntimeError("full_lens must be int32 with one entry per request")
-    sz = index_sizes(cu_h, sl_h, si, sl, last, block_m, block_n, mode, chunk_tiles, tri_min_len, fl_h)
+    if leave_dense and mode != MODES["causal"]:
+        raise RuntimeError("leave_dense goes with the causal mode")
+    dense_from = _lib.TMX_DENSE_MIN_ROWS if leave_dense else 0
+    sz = index_sizes(cu_h, sl_h, si, sl, last, block_m, block_n, mode, chunk_tiles, tri_min_len, fl_h, dense_from)
     R, nnz, n_items, n_split = (int(sz.num_qblocks), int(sz.nnz_tiles), int(sz.num_items),
                                 int(sz.num_split_qblocks))
     if block_table is not None:
@@ -298,6 +308,7 @@ def build_block_index(cu_seqlens_q: torch.Tensor, seq_lens: torch.Tensor, cu_seq
         c.tile_pages, c.pages_block_table, c.pages_block_table_stride, c.pages_page_size = None, None, 0, 0
     c.full_lens = None if full_lens is None else full_lens.data_ptr()
     c.full_lens_host = None if fl_h is None else _np_ptr(fl_h)
+    c.dense_rows_from, c.reserved = dense_from, 0
     idx = BlockIndex(buf, off, sz, c, batch, block_m, block_n, mode, si, sl, last, chunk_tiles, tri_min_len,
                      block_table, full_lens, fl_h)
     if mode == MODES["causal"]:
@@ -322,6 +333,17 @@ def dense_stage_rows(cu_seqlens_q_cpu, seq_lens_cpu, min_rows_per_request: int =
     if cu.shape[0] != sl_.shape[0] + 1:
         raise RuntimeError("cu_seqlens_q must have one entry more than seq_lens")
     return int(_lib.load().tmx_dense_stage_rows(_np_ptr(cu), _np_ptr(sl_), int(sl_.shape[0]), int(min_rows_per_request)))
+
+
+def without_dense_requests(cu_seqlens_q_cpu, seq_lens_cpu):
+    """The host batch description as an index built with ``leave_dense`` sees it: requests with
+    ``TMX_DENSE_MIN_ROWS`` query rows or more have no rows (their sequence shrinks to its context).  For the
+    scheduling advice (``suggest_chunk_tiles``) of such an index."""
+    cu = np.asarray(cu_seqlens_q_cpu, dtype=np.int64)
+    sl_ = np.asarray(seq_lens_cpu, dtype=np.int64)
+    q = np.diff(cu)
+    keep = np.where(q >= _lib.TMX_DENSE_MIN_ROWS, 0, q)
+    return (np.concatenate([[0], np.cumsum(keep)]).astype(np.int32), (sl_ - (q - keep)).astype(np.int32))
 
 
 def alloc_kv_stage(rows: int, num_kv_heads: int, device) -> Optional[torch.Tensor]:
@@ -430,7 +452,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
                                     tile_pages, part_o, part_ml, bias, float(scale),
                                     index.si, index.sl, index.last, index.mode, index.tri_min_len, index.chunk_tiles,
                                     n_items, n_part, n_split, index.full_lens, int(flags), nnz, k_new, v_new, cache_slots,
-                                    float(k_scale), float(v_scale), index.block_m, index.block_n, kv_stage)
+                                    float(k_scale), float(v_scale), index.block_m, index.block_n, kv_stage,
+                                    int(index.c.dense_rows_from))
         except RuntimeError as e:
             raise _lib.TmxError(-1, str(e)) from None
         index.built = True
