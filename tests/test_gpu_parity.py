@@ -589,6 +589,7 @@ def test_empty_inputs():
     (131072, True, 8, 2, "bf16", "triangle"),   # a 128k-token prompt (the index is then built by two launches)
     (32768, True, 32, 8, "bf16", "causal"),     # Qwen3-8B, 32k prompt on a layer outside the triangle set: dense kernel
     (8192, True, 8, 2, "fp8", "causal"),        # dense kernel out of an fp8 cache
+    (131072, True, 8, 2, "bf16", "causal"),     # a 128k-token prompt on a causal layer: staged dense kernel, 2,048 tiles per row block
 ])
 def test_attention_properties_at_full_size(n, paged, H, Hkv, cache, mode):
     """Size-independent properties at the BASELINE sizes and head shards (N = 8192 contiguous K/V; the others
@@ -622,7 +623,8 @@ def test_attention_properties_at_full_size(n, paged, H, Hkv, cache, mode):
     pat = (4, 32, 64) if mode == "triangle" else (0, 0, 0)
     idx = ops.build_block_index(cu, sld, cu_h, sl_h, *pat, ops.attention_block_m(H, Hkv), 32, ops.MODES[mode],
                                 chunk_tiles=32 if mode == "triangle" else 64,
-                                block_table=bt if in_kernel_pages else None, page_size=page if in_kernel_pages else 0)
+                                block_table=bt if in_kernel_pages else None, page_size=page if in_kernel_pages else 0,
+                                leave_dense=mode == "causal")  # (what the backend builds for a causal layer: no tile lists)
     # work areas of the calls below; a causal launch of this length gets the dense kernel's staging area (the library's
     # own rule) and runs the staged form: K/V rows gathered first, tiles by LDS-DMA
     ws = ops.alloc_workspace(idx, H, D, DEV, num_kv_heads=Hkv)
