@@ -592,7 +592,7 @@ def test_empty_inputs():
     (131072, True, 8, 2, "bf16", "causal"),     # a 128k-token prompt on a causal layer: staged dense kernel, 2,048 tiles per row block
 ])
 def test_attention_properties_at_full_size(n, paged, H, Hkv, cache, mode):
-    """Size-independent properties at the BASELINE sizes and head shards (N = 8192 contiguous K/V; the others
+    """Size-independent properties at the sizes and head shards of the benchmark configurations (N = 8192 contiguous K/V; the others
     with the paged cache and shuffled block table of the benchmark): the output is linear in V, a constant V
     returns that constant, and sampled rows (first rows, a middle row, rows around the start of the dense trailing
     region, the last row) equal the fp64 oracle.  Triangle launches run on the band + work-list workgroups,
