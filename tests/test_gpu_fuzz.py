@@ -45,6 +45,15 @@ def _random_batch(rng, big):
     return [r[0] for r in reqs], [r[1] for r in reqs]
 
 
+def _stage(ops, idx, cu_h, sl_h, Hkv):
+    """A staging area for every request the dense causal kernel takes, full of NaN (None when it takes none)."""
+    idx.stage_rows = ops.dense_stage_rows(cu_h, sl_h, 0)
+    st = ops.alloc_kv_stage(idx.stage_rows, Hkv, DEV)
+    if st is not None:
+        st.fill_(float("nan"))
+    return st
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("TMX_FUZZ_SEEDS", "24")))))  # more seeds: a longer hunt
 def test_random_steps_match_the_oracle(seed):
     from vllm_trianglemix_amd import ops
@@ -77,6 +86,13 @@ def test_random_steps_match_the_oracle(seed):
         if rng.random() < 0.25:
             flags |= f
 
+    # causal launches (a stream of draws of its own): the index may leave the dense kernel's requests out where that
+    # kernel can run, and the call may lend it a staging area (for every request it takes, whatever their lengths)
+    rng2 = np.random.default_rng(seed + 424242)
+    leave = bool(mode == "causal" and D == 128 and (H // Hkv) % 4 == 0 and not (flags & TMX_ATTN_NO_DENSE)
+                 and rng2.random() < 0.5)
+    staged = bool(mode == "causal" and D == 128 and rng2.random() < 0.5)
+
     T, B = sum(q_lens), len(seq_lens)
     q = _round(orc.seeded_normal(seed * 7 + 1, (T, H, D)), dtype)
     ks = [_round(orc.seeded_normal(seed * 7 + 100 + b, (n, Hkv, D)), dtype) for b, n in enumerate(seq_lens)]
@@ -89,7 +105,7 @@ def test_random_steps_match_the_oracle(seed):
     out = torch.full((T, H, D), float("nan"), dtype=torch.float32, device=DEV)
     bm, bn = ops.attention_block_m(H, Hkv), ops.attention_block_n()
     scale = D ** -0.5
-    desc = dict(seed=seed, defer=defer, q=q_lens, n=seq_lens, heads=(H, Hkv, D), dtype=str(dtype), mode=mode, pat=pat, gate=gate,
+    desc = dict(seed=seed, defer=defer, leave=leave, staged=staged, q=q_lens, n=seq_lens, heads=(H, Hkv, D), dtype=str(dtype), mode=mode, pat=pat, gate=gate,
                 chunk=chunk, paged=paged, page=page, fused=fused, flags=flags, fp8=fp8, scales=(k_scale, v_scale),
                 full_lens=full_lens)
     fl_h = None if full_lens is None else np.asarray(full_lens, np.int32)
@@ -123,29 +139,31 @@ def test_random_steps_match_the_oracle(seed):
         # (half of the steps hand the attention call an index that is still to be built: TMX_ATTN_BUILD_INDEX)
         idx = ops.build_block_index(cu, sld, cu_h, sl_h, *pat, bm, bn, ops.MODES[mode], chunk_tiles=chunk, tri_min_len=gate,
                                     block_table=btd if resolve else None, page_size=page if resolve else 0,
-                                    full_lens=fl_d, full_lens_cpu=fl_h, defer=defer)
+                                    full_lens=fl_d, full_lens_cpu=fl_h, defer=defer, leave_dense=leave)
+        stage = _stage(ops, idx, cu_h, sl_h, Hkv) if staged else None
         if fused:
             kn, vn = to_dev(np.concatenate(k_new, 0)), to_dev(np.concatenate(v_new, 0))
             slots_d = torch.from_numpy(np.concatenate(new_slots)).to(DEV)
             ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, flags=flags, k_new=kn, v_new=vn,
-                          cache_slots=slots_d)
+                          cache_slots=slots_d, kv_stage=stage)
             # the cache now holds every row of every request
             kf, vf = kc.view(nblk * page, Hkv, D), vc.view(nblk * page, Hkv, D)
             assert torch.equal(kf[slots_d], kn) and torch.equal(vf[slots_d], vn), desc
         elif fp8:
             ops.attention(qd, kc.view(torch.float8_e4m3fn), vc.view(torch.float8_e4m3fn), out, idx, cu, sld, scale,
-                          block_table=btd, flags=flags, k_scale=k_scale, v_scale=v_scale)
+                          block_table=btd, flags=flags, k_scale=k_scale, v_scale=v_scale, kv_stage=stage)
             # the oracle attends to what the cache holds: fp8(x / scale) x scale, rounded once to the 16-bit type
             seen = lambda x, sc: _round(orc.fp8_cache_roundtrip(x, sc).astype(np.float32), dtype)  # noqa: E731
             k_ref, v_ref = [seen(k, k_scale) for k in ks], [seen(v, v_scale) for v in vs]
         else:
-            ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, flags=flags)
+            ops.attention(qd, kc, vc, out, idx, cu, sld, scale, block_table=btd, flags=flags, kv_stage=stage)
     else:
         idx = ops.build_block_index(cu, sld, cu_h, sl_h, *pat, bm, bn, ops.MODES[mode], chunk_tiles=chunk, tri_min_len=gate,
-                                    full_lens=fl_d, full_lens_cpu=fl_h, defer=defer)
+                                    full_lens=fl_d, full_lens_cpu=fl_h, defer=defer, leave_dense=leave)
+        stage = _stage(ops, idx, cu_h, sl_h, Hkv) if staged else None
         cu_k = torch.from_numpy(np.concatenate([[0], np.cumsum(seq_lens)]).astype(np.int32)).to(DEV)
         ops.attention(qd, to_dev(np.concatenate(ks, 0)), to_dev(np.concatenate(vs, 0)), out, idx, cu, sld, scale,
-                      cu_seqlens_k=cu_k, flags=flags)
+                      cu_seqlens_k=cu_k, flags=flags, kv_stage=stage)
     torch.cuda.synchronize()
     assert idx.built
     got = out.cpu().numpy()

@@ -237,7 +237,8 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
   if (ix->dense_rows_from != 0) {
     TMX_CHECK_ARG(ix->dense_rows_from == kDenseMinRows && a->mode == TMX_MODE_CAUSAL,
                   "tmx_attention: index->dense_rows_from is 0 or %d, the latter with TMX_MODE_CAUSAL only", kDenseMinRows);
-    TMX_CHECK_SUPPORTED(p.dense_on || a->total_q < kDenseMinRows,
+    // (TMX_ATTN_SHORT_QUERIES: the caller says that no request has more than 16 rows -- the index left none out)
+    TMX_CHECK_SUPPORTED(p.dense_on || a->total_q < kDenseMinRows || (a->flags & TMX_ATTN_SHORT_QUERIES),
                         "tmx_attention: the index leaves requests of %d query rows or more to the dense causal kernel, which "
                         "this call cannot run (bias, head size other than 128, query heads per K/V head not a multiple of 4, "
                         "more than %d requests, or a flag that keeps it off)", kDenseMinRows, kDenseMaxBatch);
