@@ -328,6 +328,8 @@ extern "C" int tmx_attention(const tmx_attention_args_t* a, void* stream) {
     d.kv_fp8 = fp8 ? 1 : 0;
     d.k_scale = p.k_scale;
     d.v_scale = p.v_scale;
+    TMX_CHECK_ARG(a->kv_stage == nullptr || (aligned16(a->kv_stage) && a->kv_stage_rows >= 0),
+                  "tmx_attention: kv_stage must be 16-byte aligned and kv_stage_rows non-negative");
     d.stage = a->kv_stage;
     d.stage_rows = a->kv_stage != nullptr ? a->kv_stage_rows : 0;
     const int rc = launch_dense_causal(d, a->io_dtype == TMX_BF16, paged, s);
